@@ -1,0 +1,197 @@
+"""Mesh input for the explicit linear-tet solver: legacy-VTK reader, synthetic beams, partitions.
+
+The reference reads ``Mesh_info/beam_coarse.vtk`` through meshio
+(reference ``Data_prepare.py:56-62``) and partitions elements with ParMETIS
+(``Data_prepare.py:82-101``).  Neither library is available to this build, so this
+module provides
+
+* :func:`read_vtk` – a reader for the legacy ASCII ``UNSTRUCTURED_GRID`` files Gmsh
+  writes (only what the path needs: points, ``tetra`` cells and ``triangle`` facets),
+* :func:`structured_beam` – the deterministic synthetic ``25n x n x n`` cantilever of
+  ``SURVEY.md`` §8(d): cubes split into 6 positively oriented Kuhn tetrahedra over the
+  box of ``Mesh_info/beam_US.geo:2-16``,
+* :func:`slab_partition` / :func:`rcb_partition` – element partition vectors playing the
+  role of ``part_mesh_kway``'s ``epart`` (one part per GPU).
+
+Everything here is vectorised NumPy and O(N log N) at worst.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+# VTK cell type ids -> meshio-style names (the reference indexes cells_dict by name,
+# Data_prepare.py:59-60)
+_VTK_TYPES = {1: "vertex", 3: "line", 5: "triangle", 10: "tetra"}
+
+
+class Mesh:
+    """Minimal stand-in for the object ``meshio.read`` returns (``.points``, ``.cells_dict``)."""
+
+    def __init__(self, points, cells_dict):
+        self.points = np.ascontiguousarray(points, dtype=np.float64)
+        self.cells_dict = {k: np.ascontiguousarray(v, dtype=np.int64) for k, v in cells_dict.items()}
+
+    @property
+    def tets(self):
+        return self.cells_dict["tetra"]
+
+    @property
+    def triangles(self):
+        return self.cells_dict.get("triangle", np.zeros((0, 3), dtype=np.int64))
+
+
+def read_vtk(path) -> Mesh:
+    """Parse a legacy ASCII VTK unstructured grid (the format of ``beam_coarse.vtk``)."""
+    with open(path, "r") as fh:
+        tok = fh.read().split()
+    up = [t.upper() for t in tok]
+    try:
+        ip = up.index("POINTS")
+        ic = up.index("CELLS")
+        it = up.index("CELL_TYPES")
+    except ValueError as exc:  # pragma: no cover - malformed input
+        raise ValueError(f"{path}: not a legacy VTK UNSTRUCTURED_GRID file") from exc
+    if "ASCII" not in up[:ic]:
+        raise ValueError(f"{path}: only ASCII legacy VTK is supported")
+    n_pts = int(tok[ip + 1])
+    pts = np.array(tok[ip + 3: ip + 3 + 3 * n_pts], dtype=np.float64).reshape(n_pts, 3)
+    n_cells, n_ints = int(tok[ic + 1]), int(tok[ic + 2])
+    flat = np.array(tok[ic + 3: ic + 3 + n_ints], dtype=np.int64)
+    types = np.array(tok[it + 2: it + 2 + n_cells], dtype=np.int64)
+    if int(tok[it + 1]) != n_cells:
+        raise ValueError(f"{path}: CELL_TYPES count differs from CELLS count")
+    # walk the ragged CELLS list once
+    sizes = np.empty(n_cells, dtype=np.int64)
+    starts = np.empty(n_cells, dtype=np.int64)
+    pos = 0
+    for c in range(n_cells):
+        sizes[c] = flat[pos]
+        starts[c] = pos + 1
+        pos += 1 + flat[pos]
+    cells = {}
+    for vtk_id, name in _VTK_TYPES.items():
+        sel = np.nonzero(types == vtk_id)[0]
+        if sel.size == 0:
+            continue
+        width = int(sizes[sel[0]])
+        idx = starts[sel][:, None] + np.arange(width)[None, :]
+        cells[name] = flat[idx]
+    return Mesh(pts, cells)
+
+
+# Kuhn (Freudenthal) split of the unit cube: one tet per axis permutation, each a
+# lattice path 000 -> 111.  Odd permutations get two vertices swapped so that
+# det[x1-x0, x2-x0, x3-x0] > 0 (the reference keeps detJ signed,
+# Mat_construction.py:93, and beam_coarse has detJ > 0 everywhere).
+def _kuhn_corners():
+    import itertools
+
+    tets = []
+    for perm in itertools.permutations(range(3)):
+        v = np.zeros(3, dtype=np.int64)
+        path = [v.copy()]
+        for ax in perm:
+            v[ax] += 1
+            path.append(v.copy())
+        path = np.array(path)
+        jac = (path[1:] - path[0]).T.astype(float)
+        if np.linalg.det(jac) < 0:
+            path[[2, 3]] = path[[3, 2]]
+        tets.append(path)
+    return np.array(tets)  # (6, 4, 3) corner offsets
+
+
+def structured_beam(n: int, length: float = 25.0, width: float = 1.0, height: float = 1.0) -> Mesh:
+    """``25n x n x n`` cubes x 6 Kuhn tets on ``[0,L]x[0,W]x[0,H]``.
+
+    Node ids are lexicographic ``(ix*(ny+1) + iy)*(nz+1) + iz``; the ``x = 0`` face is
+    triangulated too so that the reference's clamp detection (``Data_prepare.py:127-136``)
+    has facets to look at.  n=19 -> 1 028 850 tets / 190 400 nodes; n=38 -> 8 230 800 / 1 446 471.
+    """
+    if n < 1:
+        raise ValueError("n must be >= 1")
+    nx, ny, nz = int(round(length / width)) * n, n, n
+    gx = np.linspace(0.0, length, nx + 1)
+    gy = np.linspace(0.0, width, ny + 1)
+    gz = np.linspace(0.0, height, nz + 1)
+    X, Y, Z = np.meshgrid(gx, gy, gz, indexing="ij")
+    pts = np.stack([X.ravel(), Y.ravel(), Z.ravel()], axis=1)
+
+    def nid(ix, iy, iz):
+        return (ix * (ny + 1) + iy) * (nz + 1) + iz
+
+    ci, cj, ck = np.meshgrid(np.arange(nx), np.arange(ny), np.arange(nz), indexing="ij")
+    ci, cj, ck = ci.ravel(), cj.ravel(), ck.ravel()
+    corners = _kuhn_corners()  # (6,4,3)
+    tets = np.empty((ci.size, 6, 4), dtype=np.int64)
+    for t in range(6):
+        for a in range(4):
+            o = corners[t, a]
+            tets[:, t, a] = nid(ci + o[0], cj + o[1], ck + o[2])
+    tets = tets.reshape(-1, 4)
+
+    # facets on x = 0: two triangles per boundary square
+    fj, fk = np.meshgrid(np.arange(ny), np.arange(nz), indexing="ij")
+    fj, fk = fj.ravel(), fk.ravel()
+    z0 = np.zeros_like(fj)
+    tri = np.concatenate([
+        np.stack([nid(z0, fj, fk), nid(z0, fj + 1, fk), nid(z0, fj + 1, fk + 1)], axis=1),
+        np.stack([nid(z0, fj, fk), nid(z0, fj + 1, fk + 1), nid(z0, fj, fk + 1)], axis=1),
+    ])
+    return Mesh(pts, {"tetra": tets, "triangle": tri})
+
+
+def clamp_nodes(mesh: Mesh, tol: float = 1e-9) -> np.ndarray:
+    """Nodes of facets lying on ``x = 0`` in first-seen order (``Data_prepare.py:127-136``)."""
+    tri = mesh.triangles
+    if tri.size == 0:
+        return np.zeros(0, dtype=np.int64)
+    on = np.all(np.abs(mesh.points[tri, 0]) < tol, axis=1)
+    flat = tri[on].ravel()
+    _, first = np.unique(flat, return_index=True)
+    return flat[np.sort(first)]
+
+
+def elmdist(n_elems: int, size: int) -> np.ndarray:
+    """Contiguous element ranges handed to ParMETIS (``Data_prepare.py:66-71``)."""
+    n_each = n_elems // size
+    n_left = n_elems - n_each * size
+    head = (n_each + 1) * np.arange(n_left + 1)
+    tail = (n_each + 1) * n_left + n_each * np.arange(1, size - n_left + 1)
+    return np.append(head, tail).astype(np.int64)
+
+
+def slab_partition(mesh: Mesh, n_parts: int, axis: int = 0) -> np.ndarray:
+    """Element -> part vector: ``n_parts`` slabs of (nearly) equal element count along ``axis``.
+
+    Stands in for ``part_mesh_kway``'s ``epart`` (``Data_prepare.py:94-101``); for the beam
+    it yields ``n_parts - 1`` planar interfaces, each shared by exactly two parts.
+    """
+    cent = mesh.points[mesh.tets, axis].mean(axis=1)
+    order = np.argsort(cent, kind="stable")
+    epart = np.empty(len(cent), dtype=np.int64)
+    bounds = elmdist(len(cent), n_parts)
+    for r in range(n_parts):
+        epart[order[bounds[r]: bounds[r + 1]]] = r
+    return epart
+
+
+def rcb_partition(mesh: Mesh, n_parts: int) -> np.ndarray:
+    """Recursive coordinate bisection of element centroids into ``n_parts`` parts."""
+    cent = mesh.points[mesh.tets].mean(axis=1)
+    epart = np.zeros(len(cent), dtype=np.int64)
+
+    def split(idx, first, count):
+        if count == 1:
+            epart[idx] = first
+            return
+        left = count // 2
+        ext = cent[idx].max(axis=0) - cent[idx].min(axis=0)
+        ax = int(np.argmax(ext))
+        k = (len(idx) * left) // count
+        part = np.argpartition(cent[idx, ax], k) if 0 < k < len(idx) else np.arange(len(idx))
+        split(idx[part[:k]], first, left)
+        split(idx[part[k:]], first + left, count - left)
+
+    split(np.arange(len(cent)), 0, n_parts)
+    return epart

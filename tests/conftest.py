@@ -1,0 +1,34 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+GOLDEN = os.path.join(REPO, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    with np.load(os.path.join(GOLDEN, name), allow_pickle=False) as z:
+        return {k: z[k] for k in z.files}
+
+
+@pytest.fixture(scope="session")
+def beam_coarse():
+    from synchronization_avoiding_algorithms_amd.mesh import Mesh
+
+    g = load_golden("beam_coarse_mesh.npz")
+    return Mesh(g["points"], {"tetra": g["tetra"], "triangle": g["triangle"]})
+
+
+def rel_l2(a, b):
+    a = np.asarray(a, dtype=np.float64).ravel()
+    b = np.asarray(b, dtype=np.float64).ravel()
+    nb = np.linalg.norm(b)
+    return np.linalg.norm(a - b) / nb if nb > 0 else np.linalg.norm(a)
