@@ -1,0 +1,157 @@
+/*
+ * saa_hip.h - C ABI of libsaa_hip.so: the MI355X (gfx950) implementation of the explicit
+ * linear-tetrahedral elastodynamics hot path of desResLab/Synchronization-avoiding-algorithms.
+ *
+ * The reference has no FFI: its hot path sits behind Python call signatures
+ * (SURVEY.md section 8(b)).  Each entry point below names the reference interface it replaces
+ * (file:line in /root/reference); INTEGRATION.md shows the ctypes binding a maintainer of the
+ * reference would add.  Plain pointers and sizes only; no torch / numpy types.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative SAA_E_* code otherwise; the message of the
+ *     last failure on the calling thread is returned by saa_last_error().
+ *   - "host" pointers are caller-owned CPU buffers, "dev" pointers caller-owned device buffers
+ *     (e.g. torch tensors' data_ptr()).  The library never frees caller memory.
+ *   - node / dof numbering at this boundary is ALWAYS the caller's (the rank-local first-touch
+ *     numbering of Distributed_tools.py:14-24; dof = 3*node + component, commons.py:66-71).
+ *     Internally nodes are renumbered block-wise; that never shows through the ABI.
+ *   - one handle per GPU partition; calls on one handle must be serialised by the caller.  All
+ *     device work is enqueued on the stream given to saa_set_stream (default: the null stream),
+ *     so PyTorch-ROCm and RCCL work ordered on the same stream needs no extra synchronisation.
+ *   - fp64 throughout (the reference is float64 NumPy).
+ */
+#ifndef SAA_HIP_H
+#define SAA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SAA_OK 0
+#define SAA_E_ARG (-1)     /* bad argument (null pointer, index out of range, degenerate element) */
+#define SAA_E_HIP (-2)     /* a HIP runtime call failed (no device, out of memory, launch failure) */
+#define SAA_E_STATE (-3)   /* call sequence error (e.g. step_finish without step_begin) */
+#define SAA_E_CAPACITY (-4) /* a node block does not fit the LDS budget even at the smallest size */
+
+typedef struct saa_solver saa_solver;
+
+/*
+ * Everything one rank holds after the set-up of Data_prepare.py:104-209, in the caller's numbering.
+ */
+typedef struct saa_problem {
+  int32_t n_nodes;               /* len(Local_nodal_list), Data_prepare.py:104 */
+  int32_t n_elems;               /* len(Local_ele_list) */
+  const double *xyz;             /* host (n_nodes,3): Points[Local_nodal_list] */
+  const int32_t *tets;           /* host (n_elems,4): local node ids (local_mat_node of Cells rows,
+                                    Mat_construction.py:139) */
+  const double *lumped_mass;     /* host (3*n_nodes): l_M, Data_prepare.py:202 */
+  const double *f_ext;           /* host (3*n_nodes): F_rankwise (un-ramped), Data_prepare.py:201 */
+  const int32_t *dirichlet_dofs; /* host (n_dirichlet): Local_Dirichlet, Data_prepare.py:144 */
+  int32_t n_dirichlet;
+  const int32_t *shared_nodes;   /* host (n_shared): local ids of this rank's shared nodes, in the
+                                    order of `shared_nodes` (Data_prepare.py:112); defines the column
+                                    order 3*i+c of the LSTM input (Online_predictor.py:126-129) */
+  const int32_t *shared_slots;   /* host (n_shared): position of each shared node in the sorted
+                                    Global_shared list (Data_prepare.py:121-124) */
+  int32_t n_shared;
+  int32_t n_global_shared;       /* len(Global_shared); interface buffer holds 3*n_global_shared */
+  double lambda_;                /* elasticity.lmd, commons.py:17 */
+  double mu;                     /* elasticity.mu */
+  double dt;                     /* min CFL step, Data_prepare.py:147-154 */
+  double alpha;                  /* mass-proportional damping `Damp`, Data_prepare.py:41 */
+  int32_t ramp;                  /* 1: F_ext = F_rankwise*min(t,1) (Dynamic_solver.py:13); 0: constant */
+  int32_t device;                /* HIP device ordinal */
+  int32_t block_nodes;           /* target owned nodes per workgroup; 0 = automatic */
+  int32_t threads;               /* workgroup size (multiple of 64, <= 1024); 0 = automatic */
+} saa_problem;
+
+/* Statistics of the block decomposition (for DESIGN.md / bench.py roofline bookkeeping). */
+typedef struct saa_plan_stats {
+  int32_t n_blocks;
+  int32_t max_owned;        /* owned nodes of the largest block */
+  int32_t max_local;        /* owned + halo nodes of the largest block */
+  int64_t n_elem_copies;    /* sum over blocks of elements touching the block (>= n_elems) */
+  int64_t n_halo_total;     /* sum over blocks of halo nodes */
+  int32_t lds_bytes;        /* dynamic LDS per workgroup */
+  int32_t threads;          /* workgroup size in use */
+} saa_plan_stats;
+
+const char *saa_last_error(void);
+/* Library / ABI version; bumps when a signature in this header changes. */
+int32_t saa_abi_version(void);
+
+/* Build the device-resident solver for one partition.  Replaces, for this path,
+ * Local_assembly_for_stiffness (Mat_construction.py:122-150: no matrix is ever assembled) plus the
+ * per-step argument marshalling of parallel_explicit_solver_dis_pre (Dynamic_solver.py:9-10).
+ * Initial state is d0 = dn = 0, tn = 0 (Data_prepare.py:171-172,215). */
+int saa_create(const saa_problem *problem, saa_solver **out);
+int saa_destroy(saa_solver *s);
+int saa_plan_stats_get(const saa_solver *s, saa_plan_stats *out);
+
+/* Host-only plan builder (no HIP call): same decomposition saa_create uses, for CPU tests. */
+int saa_plan_host_stats(int32_t n_nodes, int32_t n_elems, const double *xyz, const int32_t *tets,
+                        int32_t block_nodes, saa_plan_stats *out);
+
+/* All later work of this handle goes to `hip_stream` (a hipStream_t; NULL = null stream). */
+int saa_set_stream(saa_solver *s, void *hip_stream);
+
+/* Time_integration_displacement(tn, dt, d0, dn) (commons.py:47-55): d0 = d^n, dn = d^(n-1). */
+int saa_set_state(saa_solver *s, const double *d0_host, const double *dn_host, double tn);
+int saa_get_state(saa_solver *s, double *d0_host, double *dn_host, double *tn);
+/* Same, into caller-owned DEVICE buffers of 3*n_nodes doubles (either may be NULL). */
+int saa_get_state_device(saa_solver *s, double *d0_dev, double *dn_dev);
+/* Replace the un-ramped external force / lumped mass (host, 3*n_nodes each; NULL = keep). */
+int saa_set_loads(saa_solver *s, const double *f_ext_host, const double *lumped_mass_host);
+
+/* f = K_local . d without K: backs `LocalK.dot(T.d0)` (Dynamic_solver.py:12).  Host in, host out,
+ * 3*n_nodes doubles each. */
+int saa_internal_force(saa_solver *s, const double *d_host, double *f_host);
+
+/* One damped central-difference update on the host-provided arrays, evaluated on the GPU in the
+ * reference's association order (Dynamic_solver.py:13-20).  Backs the drop-in
+ * parallel_explicit_solver_dis_pre when the caller owns the state. */
+int saa_cd_update(saa_solver *s, const double *f_int_host, const double *d0_host, const double *dn_host,
+                  double tn, double *d1_host);
+
+/* nsteps explicit steps with no exchange: the serial case (size == 1) and the MODEL=True branch
+ * of Dynamic_solver.py:22 without a halo overwrite.  State rotates (dn<-d0<-d1), tn += dt. */
+int saa_step(saa_solver *s, int32_t nsteps);
+
+/* Synchronised step, split around the caller's collective (replaces syn_cpus,
+ * Distributed_tools.py:77-92, by an all-reduce over the compact interface buffer):
+ *   saa_step_begin : interior + shared nodes get the local update; the partial K_r d of every
+ *                    local shared node is written to iface_dev[3*slot+c]; slots of shared nodes
+ *                    this rank does not hold stay 0.
+ *   (caller: all-reduce(sum) of iface_dev over ranks, on the same stream)
+ *   saa_step_finish: shared nodes are recomputed from the summed force (Dynamic_solver.py:26-32),
+ *                    non-local slots are re-zeroed, state rotates, tn += dt.  If hist_dev != NULL the
+ *                    new shared-dof values are also written to hist_dev[hist_row*3*n_shared + ...]
+ *                    (Online_predictor.py:260). */
+int saa_set_interface_buffer(saa_solver *s, double *iface_dev);
+int saa_step_begin(saa_solver *s);
+int saa_step_finish(saa_solver *s, double *hist_dev, int64_t hist_row);
+
+/* nsteps sync-free steps of the predicted phase (Online_predictor.py:287-316): after each local
+ * update the shared dofs are overwritten by row (table_row0 + k) of table_dev (row length
+ * 3*n_shared, fp64) and recorded into row (hist_row0 + k) of hist_dev (may be NULL). */
+int saa_step_predicted(saa_solver *s, int32_t nsteps, const double *table_dev, int64_t table_row0,
+                       double *hist_dev, int64_t hist_row0);
+
+/* d_sol_shared[i,:] = d0[loc_dof_shared] (Online_predictor.py:260,301) / the reverse overwrite
+ * (:298) on the CURRENT d0, for callers that drive single steps themselves. */
+int saa_halo_gather(saa_solver *s, double *row_dev);
+int saa_halo_scatter(saa_solver *s, const double *row_dev);
+
+/* Blocks until all work enqueued for this handle has finished. */
+int saa_synchronize(saa_solver *s);
+
+/* Timing aid for bench.py: runs `nsteps` saa_step steps bracketed by HIP events recorded on the
+ * handle's stream and returns the elapsed milliseconds (kernel time incl. launch gaps). */
+int saa_time_steps(saa_solver *s, int32_t nsteps, double *elapsed_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SAA_HIP_H */

@@ -1,0 +1,131 @@
+"""ctypes binding of ``libsaa_hip.so`` (C ABI in ``include/saa_hip.h``) and its in-tree build.
+
+There is no CPU fallback: if the library cannot be loaded every compute entry point raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import shutil
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(_HERE, "libsaa_hip.so")
+HEADER = os.path.join(os.path.dirname(_HERE), "include", "saa_hip.h")
+SOURCES = ["saa_plan.cpp", "saa_kernels.hip", "saa_api.cpp"]
+HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics"]
+
+SAA_OK, SAA_E_ARG, SAA_E_HIP, SAA_E_STATE, SAA_E_CAPACITY = 0, -1, -2, -3, -4
+
+
+class SaaError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"libsaa_hip error {code}: {message}")
+        self.code = code
+
+
+class Problem(C.Structure):
+    _fields_ = [
+        ("n_nodes", C.c_int32), ("n_elems", C.c_int32),
+        ("xyz", C.POINTER(C.c_double)), ("tets", C.POINTER(C.c_int32)),
+        ("lumped_mass", C.POINTER(C.c_double)), ("f_ext", C.POINTER(C.c_double)),
+        ("dirichlet_dofs", C.POINTER(C.c_int32)), ("n_dirichlet", C.c_int32),
+        ("shared_nodes", C.POINTER(C.c_int32)), ("shared_slots", C.POINTER(C.c_int32)),
+        ("n_shared", C.c_int32), ("n_global_shared", C.c_int32),
+        ("lambda_", C.c_double), ("mu", C.c_double), ("dt", C.c_double), ("alpha", C.c_double),
+        ("ramp", C.c_int32), ("device", C.c_int32), ("block_nodes", C.c_int32), ("threads", C.c_int32),
+    ]
+
+
+class PlanStats(C.Structure):
+    _fields_ = [
+        ("n_blocks", C.c_int32), ("max_owned", C.c_int32), ("max_local", C.c_int32),
+        ("n_elem_copies", C.c_int64), ("n_halo_total", C.c_int64),
+        ("lds_bytes", C.c_int32), ("threads", C.c_int32),
+    ]
+
+    def as_dict(self):
+        return {name: int(getattr(self, name)) for name, _ in self._fields_}
+
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+_H = C.c_void_p
+
+#: name -> (restype, argtypes); must list every function declared in include/saa_hip.h
+SIGNATURES = {
+    "saa_last_error": (C.c_char_p, []),
+    "saa_abi_version": (C.c_int32, []),
+    "saa_create": (C.c_int, [C.POINTER(Problem), C.POINTER(_H)]),
+    "saa_destroy": (C.c_int, [_H]),
+    "saa_plan_stats_get": (C.c_int, [_H, C.POINTER(PlanStats)]),
+    "saa_plan_host_stats": (C.c_int, [C.c_int32, C.c_int32, _dp, _ip, C.c_int32, C.POINTER(PlanStats)]),
+    "saa_set_stream": (C.c_int, [_H, C.c_void_p]),
+    "saa_set_state": (C.c_int, [_H, _dp, _dp, C.c_double]),
+    "saa_get_state": (C.c_int, [_H, _dp, _dp, _dp]),
+    "saa_get_state_device": (C.c_int, [_H, C.c_void_p, C.c_void_p]),
+    "saa_set_loads": (C.c_int, [_H, _dp, _dp]),
+    "saa_internal_force": (C.c_int, [_H, _dp, _dp]),
+    "saa_cd_update": (C.c_int, [_H, _dp, _dp, _dp, C.c_double, _dp]),
+    "saa_step": (C.c_int, [_H, C.c_int32]),
+    "saa_set_interface_buffer": (C.c_int, [_H, C.c_void_p]),
+    "saa_step_begin": (C.c_int, [_H]),
+    "saa_step_finish": (C.c_int, [_H, C.c_void_p, C.c_int64]),
+    "saa_step_predicted": (C.c_int, [_H, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]),
+    "saa_halo_gather": (C.c_int, [_H, C.c_void_p]),
+    "saa_halo_scatter": (C.c_int, [_H, C.c_void_p]),
+    "saa_synchronize": (C.c_int, [_H]),
+    "saa_time_steps": (C.c_int, [_H, C.c_int32, _dp]),
+}
+
+_lib = None
+
+
+def needs_build() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = [os.path.join(_CSRC, f) for f in os.listdir(_CSRC)] + [HEADER]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_library(force: bool = False, verbose: bool = False) -> str:
+    """Compile the HIP sources for gfx950 into ``libsaa_hip.so`` next to this file (in-tree)."""
+    if not force and not needs_build():
+        return LIB_PATH
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        raise RuntimeError("hipcc not found: libsaa_hip.so cannot be built")
+    cmd = [hipcc, *HIPCC_FLAGS, "saa_plan.cpp", "saa_kernels.hip", "-x", "hip", "saa_api.cpp", "-o", LIB_PATH + ".tmp"]
+    res = subprocess.run(cmd, cwd=_CSRC, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + res.stderr)
+    if verbose and res.stderr:
+        print(res.stderr)
+    os.replace(LIB_PATH + ".tmp", LIB_PATH)
+    return LIB_PATH
+
+
+def load():
+    """Load the library (once) and attach the prototypes.  Raises if it is missing - no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(the HIP extension is mandatory; there is no CPU fallback)")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(code: int):
+    if code != 0:
+        msg = load().saa_last_error()
+        raise SaaError(code, msg.decode() if msg else "")

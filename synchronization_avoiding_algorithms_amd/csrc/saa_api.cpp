@@ -1,0 +1,538 @@
+// C ABI of libsaa_hip.so (see include/saa_hip.h): handle management, host<->device marshalling in the
+// caller's numbering, step sequencing.  All numerics live in saa_kernels.hip.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/saa_hip.h"
+#include "saa_device.h"
+#include "saa_plan.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string &msg) {
+  g_last_error = msg;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                      \
+  do {                                                                                     \
+    hipError_t e_ = (expr);                                                                \
+    if (e_ != hipSuccess)                                                                  \
+      return fail(SAA_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));           \
+  } while (0)
+
+constexpr int kLdsBudget = 160 * 1024;
+
+template <typename T>
+struct DevBuf {
+  T *p = nullptr;
+  size_t n = 0;
+  hipError_t alloc(size_t count) {
+    n = count;
+    if (count == 0) return hipSuccess;
+    return hipMalloc(reinterpret_cast<void **>(&p), count * sizeof(T));
+  }
+  hipError_t upload(const std::vector<T> &h) {
+    hipError_t e = alloc(h.size());
+    if (e != hipSuccess || h.empty()) return e;
+    return hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice);
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+};
+
+}  // namespace
+
+struct saa_solver {
+  saa::Plan plan;
+  int device = 0;
+  int threads = 0, lds_bytes = 0;
+  hipStream_t stream = nullptr;
+  saa::DeviceMesh mesh{};
+  saa::SharedMap shared{};
+  saa::StepConsts consts{};
+  int ramp = 1;
+  double tn = 0.0;
+  // device storage
+  DevBuf<saa::BlockDesc> blocks;
+  DevBuf<int32_t> halo_ids, tag, new_to_old, sh_node, sh_slot, sh_foreign;
+  DevBuf<uint16_t> conn;
+  DevBuf<double> xyz, mass, fext;
+  DevBuf<double> dbuf[3];
+  DevBuf<double> scratch[4];
+  int i0 = 0, in_ = 1, i1 = 2;  // dbuf indices of d^n, d^(n-1), d^(n+1)
+  double *iface = nullptr;
+  bool pending = false;
+  int32_t n_shared = 0, n_global_shared = 0;
+  std::vector<double> host_tmp;
+
+  void rotate() {
+    const int old_n = in_;
+    in_ = i0;
+    i0 = i1;
+    i1 = old_n;
+  }
+  void set_ramp() { consts.ramp = ramp ? (tn <= 1 ? tn : 1.0) : 1.0; }  // commons.py:7-11
+  void release_all() {
+    blocks.release(); halo_ids.release(); tag.release(); new_to_old.release(); sh_node.release();
+    sh_slot.release(); sh_foreign.release(); conn.release(); xyz.release(); mass.release(); fext.release();
+    for (auto &b : dbuf) b.release();
+    for (auto &b : scratch) b.release();
+  }
+};
+
+namespace {
+
+int pick_threads(const saa::Plan &plan, int requested) {
+  if (requested > 0) return requested;
+  int max_elem = 0;
+  for (const auto &b : plan.blocks) max_elem = std::max(max_elem, b.n_elem);
+  if (max_elem >= 2048) return 512;
+  if (max_elem >= 512) return 256;
+  if (max_elem >= 128) return 128;
+  return 64;
+}
+
+int lds_bytes_of(const saa::Plan &plan) { return 8 * (6 * plan.max_local + 3 * plan.max_owned); }
+
+void fill_stats(const saa::Plan &plan, int lds, int threads, saa_plan_stats *out) {
+  out->n_blocks = static_cast<int32_t>(plan.blocks.size());
+  out->max_owned = plan.max_owned;
+  out->max_local = plan.max_local;
+  out->n_elem_copies = plan.n_elem_copies;
+  out->n_halo_total = plan.n_halo_total;
+  out->lds_bytes = lds;
+  out->threads = threads;
+}
+
+bool build_fitting_plan(int32_t n_nodes, int32_t n_elems, const double *xyz, const int32_t *tets,
+                        int32_t block_nodes, saa::Plan &plan, std::string &err) {
+  int32_t bn = block_nodes > 0 ? block_nodes : saa::kDefaultBlockNodes;
+  while (true) {
+    if (!saa::build_plan(n_nodes, n_elems, xyz, tets, bn, plan, err)) return false;
+    if (lds_bytes_of(plan) <= kLdsBudget) return true;
+    if (bn <= 8) {
+      err = "node blocks do not fit the 160 KiB LDS budget";
+      return false;
+    }
+    bn /= 2;
+  }
+}
+
+// host vector in caller order -> internal order
+void permute_in(const saa::Plan &plan, const double *host, std::vector<double> &out) {
+  out.resize(3 * static_cast<size_t>(plan.n_nodes));
+  for (int32_t i = 0; i < plan.n_nodes; ++i) {
+    const size_t o = 3 * static_cast<size_t>(plan.new_to_old[i]);
+    out[3 * static_cast<size_t>(i) + 0] = host[o + 0];
+    out[3 * static_cast<size_t>(i) + 1] = host[o + 1];
+    out[3 * static_cast<size_t>(i) + 2] = host[o + 2];
+  }
+}
+
+void permute_out(const saa::Plan &plan, const std::vector<double> &in, double *host) {
+  for (int32_t i = 0; i < plan.n_nodes; ++i) {
+    const size_t o = 3 * static_cast<size_t>(plan.new_to_old[i]);
+    host[o + 0] = in[3 * static_cast<size_t>(i) + 0];
+    host[o + 1] = in[3 * static_cast<size_t>(i) + 1];
+    host[o + 2] = in[3 * static_cast<size_t>(i) + 2];
+  }
+}
+
+int upload_permuted(saa_solver *s, const double *host, double *dev) {
+  permute_in(s->plan, host, s->host_tmp);
+  HIP_TRY(hipMemcpyAsync(dev, s->host_tmp.data(), s->host_tmp.size() * sizeof(double), hipMemcpyHostToDevice,
+                         s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return SAA_OK;
+}
+
+int download_permuted(saa_solver *s, const double *dev, double *host) {
+  s->host_tmp.resize(3 * static_cast<size_t>(s->plan.n_nodes));
+  HIP_TRY(hipMemcpyAsync(s->host_tmp.data(), dev, s->host_tmp.size() * sizeof(double), hipMemcpyDeviceToHost,
+                         s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  permute_out(s->plan, s->host_tmp, host);
+  return SAA_OK;
+}
+
+int ensure_scratch(saa_solver *s, int count) {
+  for (int i = 0; i < count; ++i)
+    if (!s->scratch[i].p) HIP_TRY(s->scratch[i].alloc(3 * static_cast<size_t>(s->plan.n_nodes)));
+  return SAA_OK;
+}
+
+int check_launch() {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(SAA_E_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+  return SAA_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *saa_last_error(void) { return g_last_error.c_str(); }
+
+int32_t saa_abi_version(void) { return 1; }
+
+int saa_plan_host_stats(int32_t n_nodes, int32_t n_elems, const double *xyz, const int32_t *tets,
+                        int32_t block_nodes, saa_plan_stats *out) {
+  if (!out) return fail(SAA_E_ARG, "saa_plan_host_stats: null out");
+  saa::Plan plan;
+  std::string err;
+  if (!build_fitting_plan(n_nodes, n_elems, xyz, tets, block_nodes, plan, err)) return fail(SAA_E_ARG, err);
+  fill_stats(plan, lds_bytes_of(plan), pick_threads(plan, 0), out);
+  return SAA_OK;
+}
+
+int saa_create(const saa_problem *pb, saa_solver **out) {
+  if (!pb || !out) return fail(SAA_E_ARG, "saa_create: null argument");
+  *out = nullptr;
+  if (pb->n_nodes <= 0 || !pb->xyz || !pb->lumped_mass || !pb->f_ext || (pb->n_elems > 0 && !pb->tets))
+    return fail(SAA_E_ARG, "saa_create: empty problem or null array");
+  if ((pb->n_dirichlet > 0 && !pb->dirichlet_dofs) || (pb->n_shared > 0 && (!pb->shared_nodes || !pb->shared_slots)))
+    return fail(SAA_E_ARG, "saa_create: null index list with non-zero length");
+  if (pb->n_dirichlet < 0 || pb->n_shared < 0 || pb->n_global_shared < pb->n_shared)
+    return fail(SAA_E_ARG, "saa_create: inconsistent list lengths");
+  if (!(pb->dt > 0) || !std::isfinite(pb->dt) || !std::isfinite(pb->alpha) || !std::isfinite(pb->lambda_) ||
+      !std::isfinite(pb->mu))
+    return fail(SAA_E_ARG, "saa_create: dt must be positive and material parameters finite");
+  if (pb->threads != 0 && (pb->threads % 64 != 0 || pb->threads < 64 || pb->threads > 1024))
+    return fail(SAA_E_ARG, "saa_create: threads must be a multiple of 64 in [64,1024]");
+  if (pb->n_global_shared >= (1 << (31 - saa::kTagSlotShift)))
+    return fail(SAA_E_ARG, "saa_create: too many global shared nodes");
+  for (int32_t i = 0; i < pb->n_dirichlet; ++i)
+    if (pb->dirichlet_dofs[i] < 0 || pb->dirichlet_dofs[i] >= 3 * pb->n_nodes)
+      return fail(SAA_E_ARG, "saa_create: Dirichlet dof out of range");
+  for (int32_t i = 0; i < pb->n_shared; ++i)
+    if (pb->shared_nodes[i] < 0 || pb->shared_nodes[i] >= pb->n_nodes || pb->shared_slots[i] < 0 ||
+        pb->shared_slots[i] >= pb->n_global_shared)
+      return fail(SAA_E_ARG, "saa_create: shared node or slot out of range");
+  for (int64_t i = 0; i < 3 * static_cast<int64_t>(pb->n_nodes); ++i)
+    if (!(pb->lumped_mass[i] != 0.0) || !std::isfinite(pb->lumped_mass[i]) || !std::isfinite(pb->f_ext[i]))
+      return fail(SAA_E_ARG, "saa_create: lumped mass must be non-zero and loads finite");
+
+  saa_solver *s = new (std::nothrow) saa_solver();
+  if (!s) return fail(SAA_E_HIP, "saa_create: out of host memory");
+  std::string err;
+  if (!build_fitting_plan(pb->n_nodes, pb->n_elems, pb->xyz, pb->tets, pb->block_nodes, s->plan, err)) {
+    delete s;
+    return fail(err.find("LDS") != std::string::npos ? SAA_E_CAPACITY : SAA_E_ARG, err);
+  }
+  // degenerate elements would divide by zero in the kernel (the reference would fail in np.linalg.inv)
+  for (int32_t e = 0; e < pb->n_elems; ++e) {
+    const double *x0 = pb->xyz + 3 * static_cast<int64_t>(pb->tets[4 * static_cast<int64_t>(e)]);
+    double ed[3][3];
+    for (int a = 0; a < 3; ++a) {
+      const double *xa = pb->xyz + 3 * static_cast<int64_t>(pb->tets[4 * static_cast<int64_t>(e) + a + 1]);
+      for (int c = 0; c < 3; ++c) ed[a][c] = xa[c] - x0[c];
+    }
+    const double det = ed[0][0] * (ed[1][1] * ed[2][2] - ed[1][2] * ed[2][1]) -
+                       ed[0][1] * (ed[1][0] * ed[2][2] - ed[1][2] * ed[2][0]) +
+                       ed[0][2] * (ed[1][0] * ed[2][1] - ed[1][1] * ed[2][0]);
+    if (det == 0.0 || !std::isfinite(det)) {
+      delete s;
+      return fail(SAA_E_ARG, "saa_create: element " + std::to_string(e) + " is degenerate (detJ = 0)");
+    }
+  }
+
+#define CREATE_TRY(expr)                                                                \
+  do {                                                                                  \
+    hipError_t e_ = (expr);                                                             \
+    if (e_ != hipSuccess) {                                                             \
+      s->release_all();                                                                 \
+      delete s;                                                                         \
+      return fail(SAA_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));        \
+    }                                                                                   \
+  } while (0)
+
+  s->device = pb->device;
+  CREATE_TRY(hipSetDevice(pb->device));
+  const saa::Plan &plan = s->plan;
+  s->threads = pick_threads(plan, pb->threads);
+  s->lds_bytes = lds_bytes_of(plan);
+  CREATE_TRY(saa::configure_kernels(s->lds_bytes));
+
+  const int32_t n = plan.n_nodes;
+  std::vector<double> xyz(3 * static_cast<size_t>(n)), mass, fext;
+  permute_in(plan, pb->xyz, xyz);
+  permute_in(plan, pb->lumped_mass, mass);
+  permute_in(plan, pb->f_ext, fext);
+  std::vector<int32_t> tag(n, 0);
+  for (int32_t i = 0; i < pb->n_dirichlet; ++i) {
+    const int32_t dof = pb->dirichlet_dofs[i];
+    tag[plan.old_to_new[dof / 3]] |= 1 << (dof % 3);
+  }
+  std::vector<int32_t> sh_node(pb->n_shared), sh_slot(pb->n_shared), foreign;
+  std::vector<char> local_slot(pb->n_global_shared, 0);
+  for (int32_t i = 0; i < pb->n_shared; ++i) {
+    sh_node[i] = plan.old_to_new[pb->shared_nodes[i]];
+    sh_slot[i] = pb->shared_slots[i];
+    if (local_slot[sh_slot[i]] || (tag[sh_node[i]] & saa::kTagShared)) {
+      s->release_all();
+      delete s;
+      return fail(SAA_E_ARG, "saa_create: duplicate shared node or interface slot");
+    }
+    local_slot[sh_slot[i]] = 1;
+    tag[sh_node[i]] |= saa::kTagShared | (sh_slot[i] << saa::kTagSlotShift);
+  }
+  for (int32_t g = 0; g < pb->n_global_shared; ++g)
+    if (!local_slot[g]) foreign.push_back(g);
+
+  CREATE_TRY(s->blocks.upload(plan.blocks));
+  CREATE_TRY(s->halo_ids.upload(plan.halo_ids));
+  CREATE_TRY(s->conn.upload(plan.conn));
+  CREATE_TRY(s->new_to_old.upload(plan.new_to_old));
+  CREATE_TRY(s->xyz.upload(xyz));
+  CREATE_TRY(s->mass.upload(mass));
+  CREATE_TRY(s->fext.upload(fext));
+  CREATE_TRY(s->tag.upload(tag));
+  CREATE_TRY(s->sh_node.upload(sh_node));
+  CREATE_TRY(s->sh_slot.upload(sh_slot));
+  CREATE_TRY(s->sh_foreign.upload(foreign));
+  for (auto &b : s->dbuf) {
+    CREATE_TRY(b.alloc(3 * static_cast<size_t>(n)));
+    CREATE_TRY(hipMemset(b.p, 0, 3 * static_cast<size_t>(n) * sizeof(double)));
+  }
+#undef CREATE_TRY
+
+  s->mesh.blocks = s->blocks.p;
+  s->mesh.halo_ids = s->halo_ids.p;
+  s->mesh.conn = reinterpret_cast<const ushort4 *>(s->conn.p);
+  s->mesh.xyz = s->xyz.p;
+  s->mesh.mass = s->mass.p;
+  s->mesh.fext = s->fext.p;
+  s->mesh.tag = s->tag.p;
+  s->mesh.lambda_ = pb->lambda_;
+  s->mesh.mu = pb->mu;
+  s->mesh.n_blocks = static_cast<int32_t>(plan.blocks.size());
+  s->mesh.n_nodes = n;
+  s->mesh.max_local = plan.max_local;
+  s->mesh.max_owned = plan.max_owned;
+  s->shared.node = s->sh_node.p;
+  s->shared.slot = s->sh_slot.p;
+  s->shared.foreign_slot = s->sh_foreign.p;
+  s->shared.n_shared = pb->n_shared;
+  s->shared.n_foreign = static_cast<int32_t>(foreign.size());
+  s->n_shared = pb->n_shared;
+  s->n_global_shared = pb->n_global_shared;
+  s->ramp = pb->ramp;
+  // scalars exactly as Python forms them (Dynamic_solver.py:17): dt**2 is libm pow for numpy scalars
+  s->consts.dt = pb->dt;
+  s->consts.dt2 = std::pow(pb->dt, 2.0);
+  s->consts.half_dt = pb->dt / 2;
+  s->consts.alpha = pb->alpha;
+  s->consts.half_alpha = 0.5 * pb->alpha;
+  s->tn = 0.0;
+  *out = s;
+  return SAA_OK;
+}
+
+int saa_destroy(saa_solver *s) {
+  if (!s) return SAA_OK;
+  (void)hipSetDevice(s->device);
+  (void)hipStreamSynchronize(s->stream);
+  s->release_all();
+  delete s;
+  return SAA_OK;
+}
+
+int saa_plan_stats_get(const saa_solver *s, saa_plan_stats *out) {
+  if (!s || !out) return fail(SAA_E_ARG, "saa_plan_stats_get: null argument");
+  fill_stats(s->plan, s->lds_bytes, s->threads, out);
+  return SAA_OK;
+}
+
+int saa_set_stream(saa_solver *s, void *hip_stream) {
+  if (!s) return fail(SAA_E_ARG, "saa_set_stream: null handle");
+  s->stream = static_cast<hipStream_t>(hip_stream);
+  return SAA_OK;
+}
+
+int saa_set_state(saa_solver *s, const double *d0_host, const double *dn_host, double tn) {
+  if (!s || !d0_host || !dn_host) return fail(SAA_E_ARG, "saa_set_state: null argument");
+  if (s->pending) return fail(SAA_E_STATE, "saa_set_state: a synchronised step is in flight");
+  HIP_TRY(hipSetDevice(s->device));
+  if (int rc = upload_permuted(s, d0_host, s->dbuf[s->i0].p)) return rc;
+  if (int rc = upload_permuted(s, dn_host, s->dbuf[s->in_].p)) return rc;
+  s->tn = tn;
+  return SAA_OK;
+}
+
+int saa_get_state(saa_solver *s, double *d0_host, double *dn_host, double *tn) {
+  if (!s) return fail(SAA_E_ARG, "saa_get_state: null handle");
+  HIP_TRY(hipSetDevice(s->device));
+  if (d0_host)
+    if (int rc = download_permuted(s, s->dbuf[s->i0].p, d0_host)) return rc;
+  if (dn_host)
+    if (int rc = download_permuted(s, s->dbuf[s->in_].p, dn_host)) return rc;
+  if (tn) *tn = s->tn;
+  return SAA_OK;
+}
+
+int saa_get_state_device(saa_solver *s, double *d0_dev, double *dn_dev) {
+  if (!s) return fail(SAA_E_ARG, "saa_get_state_device: null handle");
+  HIP_TRY(hipSetDevice(s->device));
+  if (d0_dev) saa::launch_unpermute(s->plan.n_nodes, s->new_to_old.p, s->stream, s->dbuf[s->i0].p, d0_dev);
+  if (dn_dev) saa::launch_unpermute(s->plan.n_nodes, s->new_to_old.p, s->stream, s->dbuf[s->in_].p, dn_dev);
+  return check_launch();
+}
+
+int saa_set_loads(saa_solver *s, const double *f_ext_host, const double *lumped_mass_host) {
+  if (!s) return fail(SAA_E_ARG, "saa_set_loads: null handle");
+  HIP_TRY(hipSetDevice(s->device));
+  if (lumped_mass_host) {
+    for (int64_t i = 0; i < 3 * static_cast<int64_t>(s->plan.n_nodes); ++i)
+      if (!(lumped_mass_host[i] != 0.0) || !std::isfinite(lumped_mass_host[i]))
+        return fail(SAA_E_ARG, "saa_set_loads: lumped mass must be finite and non-zero");
+    if (int rc = upload_permuted(s, lumped_mass_host, s->mass.p)) return rc;
+  }
+  if (f_ext_host)
+    if (int rc = upload_permuted(s, f_ext_host, s->fext.p)) return rc;
+  return SAA_OK;
+}
+
+int saa_internal_force(saa_solver *s, const double *d_host, double *f_host) {
+  if (!s || !d_host || !f_host) return fail(SAA_E_ARG, "saa_internal_force: null argument");
+  HIP_TRY(hipSetDevice(s->device));
+  if (int rc = ensure_scratch(s, 2)) return rc;
+  if (int rc = upload_permuted(s, d_host, s->scratch[0].p)) return rc;
+  saa::launch_force_only(s->mesh, s->threads, s->lds_bytes, s->stream, s->scratch[0].p, s->scratch[1].p);
+  if (int rc = check_launch()) return rc;
+  return download_permuted(s, s->scratch[1].p, f_host);
+}
+
+int saa_cd_update(saa_solver *s, const double *f_int_host, const double *d0_host, const double *dn_host,
+                  double tn, double *d1_host) {
+  if (!s || !f_int_host || !d0_host || !dn_host || !d1_host) return fail(SAA_E_ARG, "saa_cd_update: null argument");
+  HIP_TRY(hipSetDevice(s->device));
+  if (int rc = ensure_scratch(s, 4)) return rc;
+  if (int rc = upload_permuted(s, f_int_host, s->scratch[0].p)) return rc;
+  if (int rc = upload_permuted(s, d0_host, s->scratch[1].p)) return rc;
+  if (int rc = upload_permuted(s, dn_host, s->scratch[2].p)) return rc;
+  saa::StepConsts k = s->consts;
+  k.ramp = s->ramp ? (tn <= 1 ? tn : 1.0) : 1.0;
+  saa::launch_cd_update(s->mesh, s->stream, s->scratch[0].p, s->scratch[1].p, s->scratch[2].p, s->scratch[3].p, k);
+  if (int rc = check_launch()) return rc;
+  return download_permuted(s, s->scratch[3].p, d1_host);
+}
+
+int saa_step(saa_solver *s, int32_t nsteps) {
+  if (!s || nsteps < 0) return fail(SAA_E_ARG, "saa_step: bad argument");
+  if (s->pending) return fail(SAA_E_STATE, "saa_step: a synchronised step is in flight");
+  HIP_TRY(hipSetDevice(s->device));
+  for (int32_t k = 0; k < nsteps; ++k) {
+    s->set_ramp();
+    saa::launch_fused_step(s->mesh, s->threads, s->lds_bytes, s->stream, s->dbuf[s->i0].p, s->dbuf[s->in_].p,
+                           s->dbuf[s->i1].p, nullptr, s->consts);
+    s->rotate();
+    s->tn = s->tn + s->consts.dt;  // Data_prepare.py:235
+  }
+  return check_launch();
+}
+
+int saa_set_interface_buffer(saa_solver *s, double *iface_dev) {
+  if (!s) return fail(SAA_E_ARG, "saa_set_interface_buffer: null handle");
+  if (s->pending) return fail(SAA_E_STATE, "saa_set_interface_buffer: a synchronised step is in flight");
+  s->iface = iface_dev;
+  return SAA_OK;
+}
+
+int saa_step_begin(saa_solver *s) {
+  if (!s) return fail(SAA_E_ARG, "saa_step_begin: null handle");
+  if (s->pending) return fail(SAA_E_STATE, "saa_step_begin: previous step not finished");
+  if (s->n_global_shared > 0 && !s->iface)
+    return fail(SAA_E_STATE, "saa_step_begin: no interface buffer set");
+  HIP_TRY(hipSetDevice(s->device));
+  s->set_ramp();
+  saa::launch_fused_step(s->mesh, s->threads, s->lds_bytes, s->stream, s->dbuf[s->i0].p, s->dbuf[s->in_].p,
+                         s->dbuf[s->i1].p, s->iface, s->consts);
+  s->pending = true;
+  return check_launch();
+}
+
+int saa_step_finish(saa_solver *s, double *hist_dev, int64_t hist_row) {
+  if (!s) return fail(SAA_E_ARG, "saa_step_finish: null handle");
+  if (!s->pending) return fail(SAA_E_STATE, "saa_step_finish: no step in flight");
+  if (hist_dev && hist_row < 0) return fail(SAA_E_ARG, "saa_step_finish: negative history row");
+  HIP_TRY(hipSetDevice(s->device));
+  double *row = hist_dev ? hist_dev + hist_row * 3 * static_cast<int64_t>(s->n_shared) : nullptr;
+  saa::launch_iface_finish(s->mesh, s->shared, s->stream, s->dbuf[s->i0].p, s->dbuf[s->in_].p, s->dbuf[s->i1].p,
+                           s->iface, row, s->consts);
+  s->pending = false;
+  s->rotate();
+  s->tn = s->tn + s->consts.dt;
+  return check_launch();
+}
+
+int saa_step_predicted(saa_solver *s, int32_t nsteps, const double *table_dev, int64_t table_row0,
+                       double *hist_dev, int64_t hist_row0) {
+  if (!s || nsteps < 0 || table_row0 < 0 || (hist_dev && hist_row0 < 0))
+    return fail(SAA_E_ARG, "saa_step_predicted: bad argument");
+  if (s->n_shared > 0 && !table_dev) return fail(SAA_E_ARG, "saa_step_predicted: null table");
+  if (s->pending) return fail(SAA_E_STATE, "saa_step_predicted: a synchronised step is in flight");
+  HIP_TRY(hipSetDevice(s->device));
+  const int64_t width = 3 * static_cast<int64_t>(s->n_shared);
+  for (int32_t k = 0; k < nsteps; ++k) {
+    s->set_ramp();
+    saa::launch_fused_step(s->mesh, s->threads, s->lds_bytes, s->stream, s->dbuf[s->i0].p, s->dbuf[s->in_].p,
+                           s->dbuf[s->i1].p, nullptr, s->consts);
+    saa::launch_halo_overwrite(s->shared, s->stream, table_dev + (table_row0 + k) * width, s->dbuf[s->i1].p,
+                               hist_dev ? hist_dev + (hist_row0 + k) * width : nullptr);
+    s->rotate();
+    s->tn = s->tn + s->consts.dt;
+  }
+  return check_launch();
+}
+
+int saa_halo_gather(saa_solver *s, double *row_dev) {
+  if (!s || (s->n_shared > 0 && !row_dev)) return fail(SAA_E_ARG, "saa_halo_gather: null argument");
+  HIP_TRY(hipSetDevice(s->device));
+  saa::launch_halo_gather(s->shared, s->stream, s->dbuf[s->i0].p, row_dev);
+  return check_launch();
+}
+
+int saa_halo_scatter(saa_solver *s, const double *row_dev) {
+  if (!s || (s->n_shared > 0 && !row_dev)) return fail(SAA_E_ARG, "saa_halo_scatter: null argument");
+  HIP_TRY(hipSetDevice(s->device));
+  saa::launch_halo_overwrite(s->shared, s->stream, row_dev, s->dbuf[s->i0].p, nullptr);
+  return check_launch();
+}
+
+int saa_synchronize(saa_solver *s) {
+  if (!s) return fail(SAA_E_ARG, "saa_synchronize: null handle");
+  HIP_TRY(hipSetDevice(s->device));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return SAA_OK;
+}
+
+int saa_time_steps(saa_solver *s, int32_t nsteps, double *elapsed_ms) {
+  if (!s || !elapsed_ms || nsteps < 0) return fail(SAA_E_ARG, "saa_time_steps: bad argument");
+  HIP_TRY(hipSetDevice(s->device));
+  hipEvent_t a, b;
+  HIP_TRY(hipEventCreate(&a));
+  HIP_TRY(hipEventCreate(&b));
+  HIP_TRY(hipEventRecord(a, s->stream));
+  int rc = saa_step(s, nsteps);
+  HIP_TRY(hipEventRecord(b, s->stream));
+  HIP_TRY(hipEventSynchronize(b));
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, a, b));
+  *elapsed_ms = ms;
+  (void)hipEventDestroy(a);
+  (void)hipEventDestroy(b);
+  return rc;
+}
+
+}  // extern "C"

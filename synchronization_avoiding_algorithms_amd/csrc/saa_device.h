@@ -1,0 +1,53 @@
+// Structures shared between the kernels (saa_kernels.hip) and the C-ABI layer (saa_api.cpp).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "saa_plan.h"
+
+namespace saa {
+
+// node tag: bits 0..2 = Dirichlet mask per component, bit 3 = shared node, bits 8.. = interface slot
+constexpr int32_t kTagShared = 1 << 3;
+constexpr int kTagSlotShift = 8;
+
+struct DeviceMesh {
+  const BlockDesc *blocks;
+  const int32_t *halo_ids;
+  const ushort4 *conn;
+  const double *xyz;   // (n_nodes,3) internal order
+  const double *mass;  // (3 n_nodes)
+  const double *fext;  // (3 n_nodes) un-ramped
+  const int32_t *tag;  // (n_nodes)
+  double lambda_, mu;
+  int32_t n_blocks, n_nodes, max_local, max_owned;
+};
+
+// Scalars of one step, pre-computed on the host exactly as Python evaluates them
+// (Dynamic_solver.py:13,17): dt2 = dt**2, half_dt = dt/2, half_alpha = 0.5*alpha,
+// ramp = linear_ramp(tn).
+struct StepConsts {
+  double dt, dt2, half_dt, alpha, half_alpha, ramp;
+};
+
+struct SharedMap {
+  const int32_t *node;          // (n_shared) internal node id, caller's shared order
+  const int32_t *slot;          // (n_shared) interface slot
+  const int32_t *foreign_slot;  // (n_foreign) interface slots of shared nodes held by other ranks only
+  int32_t n_shared, n_foreign;
+};
+
+hipError_t configure_kernels(int lds_bytes);
+void launch_fused_step(const DeviceMesh &m, int threads, int lds_bytes, hipStream_t st, const double *d0,
+                       const double *dn, double *d1, double *iface, const StepConsts &k);
+void launch_force_only(const DeviceMesh &m, int threads, int lds_bytes, hipStream_t st, const double *d,
+                       double *f);
+void launch_iface_finish(const DeviceMesh &m, const SharedMap &sh, hipStream_t st, const double *d0,
+                         const double *dn, double *d1, double *iface, double *hist_row, const StepConsts &k);
+void launch_halo_overwrite(const SharedMap &sh, hipStream_t st, const double *row, double *d1, double *hist_row);
+void launch_halo_gather(const SharedMap &sh, hipStream_t st, const double *d, double *row);
+void launch_cd_update(const DeviceMesh &m, hipStream_t st, const double *f_int, const double *d0,
+                      const double *dn, double *d1, const StepConsts &k);
+void launch_unpermute(int n_nodes, const int32_t *new_to_old, hipStream_t st, const double *in, double *out);
+
+}  // namespace saa

@@ -1,0 +1,309 @@
+// gfx950 (MI355X / CDNA4) kernels of the explicit linear-tet elastodynamics step.
+//
+// One fused kernel per time step (fused_step_kernel): a workgroup owns a contiguous block of nodes,
+//   1. stages coordinates + displacement d^n of its owned and halo nodes in LDS (48-byte records),
+//   2. evaluates every element touching an owned node, matrix-free:
+//          f_a = (detJ/6) * sigma(grad u) * gradN_a        [= K_e d restricted to node a]
+//      (closed form of Local_K_coronary, /root/reference Tools/Mat_construction.py:79-119, with the
+//      B-matrix convention of :99-104; the 4-point rule of Tools/Qudrature.py:7-12 is exact for the
+//      constant integrand, weights sum to 1/6) and accumulates f_a of OWNED nodes in LDS
+//      (ds_add_f64) - no global atomics, no force vector in HBM,
+//   3. applies the damped central-difference update of Tools/Dynamic_solver.py:13-20 to its owned
+//      dofs in the reference's association order (no FMA contraction) and writes d^(n+1).
+// The same kernel in FORCE_ONLY mode writes f_int instead (backs LocalK.dot, Dynamic_solver.py:12).
+//
+// Bandwidth-bound gather/scatter in fp64: MFMA is not used (and fp64 MFMA has the vector rate on
+// gfx950 anyway).  64-wide waves; all cross-workgroup data flows through kernel boundaries.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "saa_device.h"
+
+namespace saa {
+
+// ---------------------------------------------------------------------------------------------
+// The update expression.  Must stay bit-identical to NumPy evaluating
+//   (dt**2*(F_ext - F_int) + 2*l_M*d0 - l_M*dn + dt/2*l_M*alpha*dn)/(l_M + 0.5*alpha*l_M*dt)
+// (Dynamic_solver.py:17): same association, every product and sum rounded separately.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double cd_update_dof(double f_int, double f_pre, double m, double d0, double dn,
+                                                const StepConsts &k) {
+#pragma clang fp contract(off)
+  const double f_ext = f_pre * k.ramp;              // F_rankwise * linear_ramp(tn)   (:13)
+  const double a = k.dt2 * (f_ext - f_int);         // dt**2*(F_ext - F_int)
+  const double b = (2.0 * m) * d0;                  // 2*l_M*d0
+  const double c = m * dn;                          // l_M*dn
+  const double d = ((k.half_dt * m) * k.alpha) * dn;  // dt/2*l_M*alpha*dn
+  const double num = ((a + b) - c) + d;
+  const double den = m + (k.half_alpha * m) * k.dt;  // l_M + 0.5*alpha*l_M*dt
+  return num / den;
+}
+
+// Internal force of one linear tet on its nodes 1..3 (node 0 gets minus their sum).
+// x*, u*: coordinates / displacements of the 4 nodes.  lam, mu: Lame parameters.
+struct Vec3 {
+  double x, y, z;
+};
+__device__ __forceinline__ Vec3 sub(const Vec3 &a, const Vec3 &b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ Vec3 cross(const Vec3 &a, const Vec3 &b) {
+  return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+
+__device__ __forceinline__ void tet_forces(const Vec3 &x0, const Vec3 &x1, const Vec3 &x2, const Vec3 &x3,
+                                           const Vec3 &u0, const Vec3 &u1, const Vec3 &u2, const Vec3 &u3,
+                                           double lam, double mu, Vec3 &f1, Vec3 &f2, Vec3 &f3) {
+  // J columns are the edges x_a - x_0 (Shape_function_Deriv.py:60-67); gradN_a = c_a / detJ with
+  // c_1 = e2 x e3, c_2 = e3 x e1, c_3 = e1 x e2 (rows of adj J), detJ = e1 . c_1 (signed, :93).
+  const Vec3 e1 = sub(x1, x0), e2 = sub(x2, x0), e3 = sub(x3, x0);
+  const Vec3 c1 = cross(e2, e3), c2 = cross(e3, e1), c3 = cross(e1, e2);
+  const double det = e1.x * c1.x + e1.y * c1.y + e1.z * c1.z;
+  const double s = 1.0 / (6.0 * det);  // (detJ/6) / detJ^2
+  const Vec3 w1 = sub(u1, u0), w2 = sub(u2, u0), w3 = sub(u3, u0);
+  // H' = detJ * grad u = sum_a w_a (x) c_a
+  const double h00 = w1.x * c1.x + w2.x * c2.x + w3.x * c3.x;
+  const double h01 = w1.x * c1.y + w2.x * c2.y + w3.x * c3.y;
+  const double h02 = w1.x * c1.z + w2.x * c2.z + w3.x * c3.z;
+  const double h10 = w1.y * c1.x + w2.y * c2.x + w3.y * c3.x;
+  const double h11 = w1.y * c1.y + w2.y * c2.y + w3.y * c3.y;
+  const double h12 = w1.y * c1.z + w2.y * c2.z + w3.y * c3.z;
+  const double h20 = w1.z * c1.x + w2.z * c2.x + w3.z * c3.x;
+  const double h21 = w1.z * c1.y + w2.z * c2.y + w3.z * c3.y;
+  const double h22 = w1.z * c1.z + w2.z * c2.z + w3.z * c3.z;
+  // sigma' * s with sigma = lam tr(eps) I + 2 mu eps (commons.py:25-31, Voigt xx,yy,zz,yz,xz,xy)
+  const double ls = lam * s, ms = mu * s, ms2 = ms + ms;
+  const double ltr = ls * (h00 + h11 + h22);
+  const double sxx = ltr + ms2 * h00, syy = ltr + ms2 * h11, szz = ltr + ms2 * h22;
+  const double syz = ms * (h12 + h21), sxz = ms * (h02 + h20), sxy = ms * (h01 + h10);
+  f1 = {sxx * c1.x + sxy * c1.y + sxz * c1.z, sxy * c1.x + syy * c1.y + syz * c1.z,
+        sxz * c1.x + syz * c1.y + szz * c1.z};
+  f2 = {sxx * c2.x + sxy * c2.y + sxz * c2.z, sxy * c2.x + syy * c2.y + syz * c2.z,
+        sxz * c2.x + syz * c2.y + szz * c2.z};
+  f3 = {sxx * c3.x + sxy * c3.y + sxz * c3.z, sxy * c3.x + syy * c3.y + syz * c3.z,
+        sxz * c3.x + syz * c3.y + szz * c3.z};
+}
+
+typedef __attribute__((address_space(3))) double lds_double;
+
+__device__ __forceinline__ void lds_add(double *p, double v) {
+  // ds_add_f64 (no return): LDS-side fp64 add
+  __builtin_amdgcn_ds_atomic_fadd_f64((lds_double *)p, v);
+}
+
+// blockIdx -> plan block.  Blocks are dealt round-robin to the 8 XCDs (blockIdx % 8 shares an XCD);
+// plan blocks are spatially ordered (RCB leaves), so give every XCD one contiguous run of them and
+// halo re-reads hit that XCD's L2.  Only a speed matter: any bijection is correct.
+__device__ __forceinline__ int plan_block(int bid, int n_blocks) {
+  const int per = n_blocks >> 3, rem = n_blocks & 7;
+  const int x = bid & 7, j = bid >> 3;
+  // XCD x owns per + (x < rem) blocks, starting after the blocks of XCDs < x
+  return x * per + (x < rem ? x : rem) + j;
+}
+
+template <bool FORCE_ONLY>
+__global__ void fused_step_kernel(DeviceMesh m, const double *__restrict__ d0, const double *__restrict__ dn,
+                                  double *__restrict__ out, double *__restrict__ iface, StepConsts k) {
+  extern __shared__ double lds[];
+  const BlockDesc bd = m.blocks[plan_block(blockIdx.x, m.n_blocks)];
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int n_loc = bd.n_owned + bd.n_halo;
+  double *rec = lds;                     // [n_loc][6]: x y z ux uy uz
+  double *acc = lds + 6 * m.max_local;   // [n_owned][3]
+
+  // ---- 1. stage owned (contiguous) and halo (indexed) node records ---------------------------
+  {
+    const double *xo = m.xyz + 3 * (int64_t)bd.node_start;
+    const double *uo = d0 + 3 * (int64_t)bd.node_start;
+    for (int i = tid; i < 3 * bd.n_owned; i += nt) {
+      const int n = i / 3, c = i - 3 * n;
+      rec[6 * n + c] = xo[i];
+      rec[6 * n + 3 + c] = uo[i];
+      acc[i] = 0.0;
+    }
+    const int32_t *hid = m.halo_ids + bd.halo_off;
+    for (int i = tid; i < 3 * bd.n_halo; i += nt) {
+      const int n = i / 3, c = i - 3 * n;
+      const int64_t g = 3 * (int64_t)hid[n] + c;
+      rec[6 * (bd.n_owned + n) + c] = m.xyz[g];
+      rec[6 * (bd.n_owned + n) + 3 + c] = d0[g];
+    }
+  }
+  __syncthreads();
+
+  // ---- 2. elements: one per lane, accumulate owned-node forces in LDS ------------------------
+  {
+    const ushort4 *conn = m.conn + bd.elem_off;
+    const int n_owned = bd.n_owned;
+    for (int e = tid; e < bd.n_elem; e += nt) {
+      const ushort4 c = conn[e];
+      const double *r0 = rec + 6 * c.x, *r1 = rec + 6 * c.y, *r2 = rec + 6 * c.z, *r3 = rec + 6 * c.w;
+      Vec3 f1, f2, f3;
+      tet_forces({r0[0], r0[1], r0[2]}, {r1[0], r1[1], r1[2]}, {r2[0], r2[1], r2[2]}, {r3[0], r3[1], r3[2]},
+                 {r0[3], r0[4], r0[5]}, {r1[3], r1[4], r1[5]}, {r2[3], r2[4], r2[5]}, {r3[3], r3[4], r3[5]},
+                 m.lambda_, m.mu, f1, f2, f3);
+      if (c.x < n_owned) {
+        lds_add(acc + 3 * c.x + 0, -(f1.x + f2.x + f3.x));
+        lds_add(acc + 3 * c.x + 1, -(f1.y + f2.y + f3.y));
+        lds_add(acc + 3 * c.x + 2, -(f1.z + f2.z + f3.z));
+      }
+      if (c.y < n_owned) {
+        lds_add(acc + 3 * c.y + 0, f1.x);
+        lds_add(acc + 3 * c.y + 1, f1.y);
+        lds_add(acc + 3 * c.y + 2, f1.z);
+      }
+      if (c.z < n_owned) {
+        lds_add(acc + 3 * c.z + 0, f2.x);
+        lds_add(acc + 3 * c.z + 1, f2.y);
+        lds_add(acc + 3 * c.z + 2, f2.z);
+      }
+      if (c.w < n_owned) {
+        lds_add(acc + 3 * c.w + 0, f3.x);
+        lds_add(acc + 3 * c.w + 1, f3.y);
+        lds_add(acc + 3 * c.w + 2, f3.z);
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- 3. owned dofs: write f_int, or update -------------------------------------------------
+  {
+    const int64_t base = 3 * (int64_t)bd.node_start;
+    for (int i = tid; i < 3 * bd.n_owned; i += nt) {
+      const double f = acc[i];
+      if (FORCE_ONLY) {
+        out[base + i] = f;
+      } else {
+        const int n = i / 3, c = i - 3 * n;
+        const int32_t tag = m.tag[bd.node_start + n];
+        if (iface != nullptr && (tag & kTagShared)) iface[3 * (int64_t)(tag >> kTagSlotShift) + c] = f;
+        double v = cd_update_dof(f, m.fext[base + i], m.mass[base + i], rec[6 * n + 3 + c], dn[base + i], k);
+        if (tag & (1 << c)) v = 0.0;  // d1[Local_Dirichlet] = 0   (Dynamic_solver.py:20)
+        out[base + i] = v;
+      }
+    }
+  }
+}
+
+template __global__ void fused_step_kernel<false>(DeviceMesh, const double *, const double *, double *,
+                                                   double *, StepConsts);
+template __global__ void fused_step_kernel<true>(DeviceMesh, const double *, const double *, double *,
+                                                  double *, StepConsts);
+
+// After the all-reduce: shared nodes get the update from the summed force (Dynamic_solver.py:26-32),
+// optional history record (Online_predictor.py:260); slots of shared nodes this rank does not hold
+// are zeroed so that the next all-reduce sees only fresh partial forces.
+__global__ void iface_finish_kernel(DeviceMesh m, SharedMap sh, const double *__restrict__ d0,
+                                    const double *__restrict__ dn, double *__restrict__ d1,
+                                    double *__restrict__ iface, double *__restrict__ hist_row, StepConsts k) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n_local = 3 * sh.n_shared;
+  if (i < n_local) {
+    const int s = i / 3, c = i - 3 * s;
+    const int node = sh.node[s];
+    const int64_t g = 3 * (int64_t)node + c;
+    const double f = iface[3 * (int64_t)sh.slot[s] + c];
+    double v = cd_update_dof(f, m.fext[g], m.mass[g], d0[g], dn[g], k);
+    if (m.tag[node] & (1 << c)) v = 0.0;
+    d1[g] = v;
+    if (hist_row) hist_row[i] = v;
+  } else if (i < n_local + 3 * sh.n_foreign) {
+    const int j = i - n_local;
+    iface[3 * (int64_t)sh.foreign_slot[j / 3] + (j % 3)] = 0.0;
+  }
+}
+
+// Predicted phase: d1[loc_dof_shared] = table row (Online_predictor.py:298), history record (:301).
+__global__ void halo_overwrite_kernel(SharedMap sh, const double *__restrict__ row, double *__restrict__ d1,
+                                      double *__restrict__ hist_row) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < 3 * sh.n_shared) {
+    const double v = row[i];
+    d1[3 * (int64_t)sh.node[i / 3] + (i % 3)] = v;
+    if (hist_row) hist_row[i] = v;
+  }
+}
+
+__global__ void halo_gather_kernel(SharedMap sh, const double *__restrict__ d, double *__restrict__ row) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < 3 * sh.n_shared) row[i] = d[3 * (int64_t)sh.node[i / 3] + (i % 3)];
+}
+
+// Standalone update on arrays in internal order (backs saa_cd_update).
+__global__ void cd_update_kernel(DeviceMesh m, const double *__restrict__ f_int, const double *__restrict__ d0,
+                                 const double *__restrict__ dn, double *__restrict__ d1, StepConsts k) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < 3 * (int64_t)m.n_nodes) {
+    const int n = (int)(i / 3), c = (int)(i - 3 * (int64_t)n);
+    double v = cd_update_dof(f_int[i], m.fext[i], m.mass[i], d0[i], dn[i], k);
+    if (m.tag[n] & (1 << c)) v = 0.0;
+    d1[i] = v;
+  }
+}
+
+// internal order -> caller order
+__global__ void unpermute_kernel(int n_nodes, const int32_t *__restrict__ new_to_old,
+                                 const double *__restrict__ in, double *__restrict__ out) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < 3 * (int64_t)n_nodes) {
+    const int n = (int)(i / 3), c = (int)(i - 3 * (int64_t)n);
+    out[3 * (int64_t)new_to_old[n] + c] = in[i];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// launchers (called from saa_api.cpp through saa_device.h)
+// ---------------------------------------------------------------------------------------------
+hipError_t configure_kernels(int lds_bytes) {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_step_kernel<false>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+  if (e != hipSuccess) return e;
+  return hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_step_kernel<true>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+}
+
+void launch_fused_step(const DeviceMesh &m, int threads, int lds_bytes, hipStream_t st, const double *d0,
+                       const double *dn, double *d1, double *iface, const StepConsts &k) {
+  hipLaunchKernelGGL(fused_step_kernel<false>, dim3(m.n_blocks), dim3(threads), lds_bytes, st, m, d0, dn, d1,
+                     iface, k);
+}
+
+void launch_force_only(const DeviceMesh &m, int threads, int lds_bytes, hipStream_t st, const double *d,
+                       double *f) {
+  StepConsts k{};
+  hipLaunchKernelGGL(fused_step_kernel<true>, dim3(m.n_blocks), dim3(threads), lds_bytes, st, m, d, d, f,
+                     static_cast<double *>(nullptr), k);
+}
+
+void launch_iface_finish(const DeviceMesh &m, const SharedMap &sh, hipStream_t st, const double *d0,
+                         const double *dn, double *d1, double *iface, double *hist_row, const StepConsts &k) {
+  const int n = 3 * (sh.n_shared + sh.n_foreign);
+  if (n == 0) return;
+  hipLaunchKernelGGL(iface_finish_kernel, dim3((n + 255) / 256), dim3(256), 0, st, m, sh, d0, dn, d1, iface,
+                     hist_row, k);
+}
+
+void launch_halo_overwrite(const SharedMap &sh, hipStream_t st, const double *row, double *d1, double *hist_row) {
+  const int n = 3 * sh.n_shared;
+  if (n == 0) return;
+  hipLaunchKernelGGL(halo_overwrite_kernel, dim3((n + 255) / 256), dim3(256), 0, st, sh, row, d1, hist_row);
+}
+
+void launch_halo_gather(const SharedMap &sh, hipStream_t st, const double *d, double *row) {
+  const int n = 3 * sh.n_shared;
+  if (n == 0) return;
+  hipLaunchKernelGGL(halo_gather_kernel, dim3((n + 255) / 256), dim3(256), 0, st, sh, d, row);
+}
+
+void launch_cd_update(const DeviceMesh &m, hipStream_t st, const double *f_int, const double *d0,
+                      const double *dn, double *d1, const StepConsts &k) {
+  const int64_t n = 3 * (int64_t)m.n_nodes;
+  hipLaunchKernelGGL(cd_update_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, m, f_int, d0, dn,
+                     d1, k);
+}
+
+void launch_unpermute(int n_nodes, const int32_t *new_to_old, hipStream_t st, const double *in, double *out) {
+  const int64_t n = 3 * (int64_t)n_nodes;
+  hipLaunchKernelGGL(unpermute_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n_nodes,
+                     new_to_old, in, out);
+}
+
+}  // namespace saa

@@ -1,0 +1,128 @@
+"""Host-side set-up of the explicit solver in O(N): what ``Data_prepare.py:104-204`` does with dense
+``(3N)^2`` matrices and O(N^2) list scans, restated with closed forms and vectorised NumPy.
+
+* lumped mass / pre-assembled load: the reference row-sums the consistent mass of
+  ``Global_Assembly_no_bc`` (``Tools/Mat_construction.py:199-231``, ``Tools/commons.py:103-107``);
+  for linear tets that is ``rho*V_e/4`` per node and ``(V_e/4)*(0,-fz,-fz)``.
+* CFL step: ``gamma * 2*min_edge/sqrt(24) / sqrt(E/rho/(1-nu^2))`` (``commons.py:79-90``,
+  ``Data_prepare.py:147``).
+* partition bookkeeping with the reference's orderings (``Tools/Distributed_tools.py:14-73``):
+  local nodes in first-touch order, shared nodes in "other ranks' first-touch" order, sorted
+  ``Global_shared``.
+
+No GPU work here; nothing in this module imports ``oracle``.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+
+import numpy as np
+
+
+def lame(E: float, nu: float):
+    """(lambda, mu) as formed at ``Data_prepare.py:47``."""
+    return E * nu / ((1 + nu) * (1 - 2 * nu)), E / (2 * (1 + nu))
+
+
+def signed_volumes(points: np.ndarray, cells: np.ndarray) -> np.ndarray:
+    """``detJ/6`` per element, sign kept like the reference (``Mat_construction.py:93``)."""
+    p = points[cells]
+    e1, e2, e3 = p[:, 1] - p[:, 0], p[:, 2] - p[:, 0], p[:, 3] - p[:, 0]
+    return np.einsum("ij,ij->i", e1, np.cross(e2, e3)) / 6.0
+
+
+def lumped_mass_and_load(points, cells, rho, fz):
+    """(lumped_M, F_pre), each ``(3N,1)`` like the arrays broadcast at ``Data_prepare.py:194-197``."""
+    n = len(points)
+    quarter = np.repeat(signed_volumes(points, cells) / 4.0, 4)
+    nodal = np.bincount(np.asarray(cells).ravel(), weights=quarter, minlength=n)
+    lumped = np.repeat(rho * nodal, 3).reshape(-1, 1)
+    load = np.outer(nodal, np.array([0.0, -fz, -fz])).reshape(-1, 1)
+    return lumped, load
+
+
+def meshsize(points, cells) -> float:
+    p = points[np.asarray(cells)]
+    best = np.inf
+    for a, b in ((0, 1), (1, 2), (2, 3), (1, 3), (0, 3), (0, 2)):
+        d = p[:, a] - p[:, b]
+        best = min(best, float(np.sqrt(np.einsum("ij,ij->i", d, d).min())))
+    return 2.0 * best / np.sqrt(24)
+
+
+def cfl_dt(points, cells, E, nu, rho, gamma) -> float:
+    return gamma * meshsize(points, cells) / np.sqrt(E / rho / (1 - nu ** 2))
+
+
+def node_to_dof(nodes) -> np.ndarray:
+    """dof = 3*node + component (``commons.py:66-71``)."""
+    nodes = np.asarray(nodes, dtype=np.int64)
+    return (3 * nodes[:, None] + np.arange(3)[None, :]).ravel()
+
+
+def first_touch_nodes(cells_of_rank: np.ndarray) -> np.ndarray:
+    """Nodes in the order a sweep over the rank's elements first meets them
+    (``rankwise_dist``, ``Distributed_tools.py:14-24``)."""
+    flat = np.asarray(cells_of_rank).ravel()
+    _, first = np.unique(flat, return_index=True)
+    return flat[np.sort(first)]
+
+
+@dataclass
+class RankLayout:
+    """What one rank knows after ``Data_prepare.py:104-144``."""
+    rank: int
+    elements: np.ndarray            # global element ids, mesh order      (Local_ele_list)
+    nodes: np.ndarray               # global node ids, first-touch order  (Local_nodal_list)
+    cells_local: np.ndarray         # (ne,4) int32 local node ids
+    shared_nodes: np.ndarray        # global ids, reference order         (shared_nodes)
+    shared_local: np.ndarray        # local ids of shared_nodes           (local_mat_node)
+    shared_slots: np.ndarray        # positions in Global_shared
+    dirichlet_dofs: np.ndarray      # local dofs                          (Local_Dirichlet)
+    loc_dof_shared: np.ndarray = field(default=None)  # Online_predictor.py:129
+
+    @property
+    def local_dof(self):
+        return node_to_dof(self.nodes)
+
+
+def build_layouts(cells: np.ndarray, epart: np.ndarray, n_parts: int, n_nodes: int,
+                  dirichlet_nodes: np.ndarray):
+    """All ranks' layouts + ``Global_shared`` (every process can do this: the mesh is replicated,
+    as in the reference, ``Data_prepare.py:76-79``)."""
+    cells = np.asarray(cells, dtype=np.int64)
+    epart = np.asarray(epart)
+    elements = [np.nonzero(epart == r)[0] for r in range(n_parts)]
+    nodes = [first_touch_nodes(cells[e]) for e in elements]
+    member = np.zeros((n_parts, n_nodes), dtype=bool)
+    for r in range(n_parts):
+        member[r, nodes[r]] = True
+    multiplicity = member.sum(axis=0)
+    global_shared = np.nonzero(multiplicity > 1)[0]           # sorted union (sort_shared, :44-51)
+    slot_of = np.full(n_nodes, -1, dtype=np.int64)
+    slot_of[global_shared] = np.arange(len(global_shared))
+    is_dirichlet = np.zeros(n_nodes, dtype=bool)
+    is_dirichlet[np.asarray(dirichlet_nodes, dtype=np.int64)] = True
+
+    layouts = []
+    for r in range(n_parts):
+        local_of = np.full(n_nodes, -1, dtype=np.int64)
+        local_of[nodes[r]] = np.arange(len(nodes[r]))
+        # find_shared_nodes (:29-40): sweep the other ranks' lists in rank order, keep first hits
+        hits = [nodes[q][member[r, nodes[q]]] for q in range(n_parts) if q != r]
+        if hits and sum(len(h) for h in hits):
+            cat = np.concatenate(hits)
+            _, first = np.unique(cat, return_index=True)
+            shared = cat[np.sort(first)]
+        else:
+            shared = np.zeros(0, dtype=np.int64)
+        shared_local = local_of[shared]
+        dloc = np.nonzero(is_dirichlet[nodes[r]])[0]             # Dirichlet_rank_dist (:55-62)
+        layouts.append(RankLayout(
+            rank=r, elements=elements[r], nodes=nodes[r],
+            cells_local=local_of[cells[elements[r]]].astype(np.int32),
+            shared_nodes=shared, shared_local=shared_local.astype(np.int32),
+            shared_slots=slot_of[shared].astype(np.int32),
+            dirichlet_dofs=node_to_dof(dloc).astype(np.int32),
+            loc_dof_shared=node_to_dof(shared_local)))
+    return layouts, global_shared

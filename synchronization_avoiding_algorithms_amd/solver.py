@@ -1,0 +1,186 @@
+"""Device-resident explicit solver: Python face of one ``saa_solver`` handle of ``libsaa_hip.so``.
+
+``HipExplicitSolver`` owns the state ``(d0, dn, tn)`` of ``Time_integration_displacement``
+(/root/reference ``Tools/commons.py:47-55``) on the GPU and advances it with the fused HIP kernel;
+arrays cross this boundary in the caller's (rank-local, first-touch) numbering only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+def _f64(a, n=None):
+    a = np.ascontiguousarray(np.asarray(a, dtype=np.float64).reshape(-1))
+    if n is not None and a.size != n:
+        raise ValueError(f"expected {n} values, got {a.size}")
+    return a
+
+
+def _i32(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.int32).reshape(-1))
+
+
+def _dptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _iptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32)) if a.size else None
+
+
+def _dev(t):
+    """Device pointer of a torch CUDA tensor (or None)."""
+    if t is None:
+        return None
+    if not (t.is_cuda and t.is_contiguous() and t.dtype.is_floating_point and t.element_size() == 8):
+        raise ValueError("device buffers must be contiguous float64 CUDA tensors")
+    return C.c_void_p(t.data_ptr())
+
+
+class HipExplicitSolver:
+    """One mesh partition on one MI355X.
+
+    Parameters follow the variables of ``Data_prepare.py:200-209``:
+    ``points`` = ``Points[Local_nodal_list]`` (n,3); ``cells`` local node ids (ne,4);
+    ``l_M`` / ``F_rankwise`` (3n,) or (3n,1); ``dirichlet_dofs`` = ``Local_Dirichlet``.
+    ``shared_local`` / ``shared_slots`` describe this rank's interface nodes
+    (:class:`fem_setup.RankLayout`), ``n_global_shared`` = ``len(Global_shared)``.
+    """
+
+    def __init__(self, points, cells, l_M, F_rankwise, dirichlet_dofs, lmd, mu, dt, alpha,
+                 shared_local=(), shared_slots=(), n_global_shared=0, ramp=True, device=0,
+                 block_nodes=0, threads=0):
+        self._lib = _lib.load()
+        self._h = C.c_void_p()
+        pts = _f64(points)
+        self.n_nodes = pts.size // 3
+        self.n_dof = 3 * self.n_nodes
+        tets = _i32(cells)
+        self.n_elems = tets.size // 4
+        mass, fext = _f64(l_M, self.n_dof), _f64(F_rankwise, self.n_dof)
+        dd, sn, ss = _i32(dirichlet_dofs), _i32(shared_local), _i32(shared_slots)
+        if sn.size != ss.size:
+            raise ValueError("shared_local and shared_slots differ in length")
+        self.n_shared = int(sn.size)
+        self.n_global_shared = int(n_global_shared)
+        self.dt = float(dt)
+        pb = _lib.Problem(
+            n_nodes=self.n_nodes, n_elems=self.n_elems, xyz=_dptr(pts), tets=_iptr(tets),
+            lumped_mass=_dptr(mass), f_ext=_dptr(fext), dirichlet_dofs=_iptr(dd), n_dirichlet=dd.size,
+            shared_nodes=_iptr(sn), shared_slots=_iptr(ss), n_shared=sn.size,
+            n_global_shared=self.n_global_shared, lambda_=float(lmd), mu=float(mu), dt=float(dt),
+            alpha=float(alpha), ramp=1 if ramp else 0, device=int(device), block_nodes=int(block_nodes),
+            threads=int(threads))
+        _lib.check(self._lib.saa_create(C.byref(pb), C.byref(self._h)))
+        self._iface = None
+
+    # -- lifetime -------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.saa_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001 - interpreter shutdown
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- plumbing -------------------------------------------------------------------------------
+    def plan_stats(self) -> dict:
+        st = _lib.PlanStats()
+        _lib.check(self._lib.saa_plan_stats_get(self._h, C.byref(st)))
+        return st.as_dict()
+
+    def set_stream(self, stream_ptr):
+        """``stream_ptr``: integer hipStream_t, e.g. ``torch.cuda.current_stream().cuda_stream``."""
+        _lib.check(self._lib.saa_set_stream(self._h, C.c_void_p(int(stream_ptr) if stream_ptr else 0)))
+
+    def synchronize(self):
+        _lib.check(self._lib.saa_synchronize(self._h))
+
+    # -- state ----------------------------------------------------------------------------------
+    def set_state(self, d0, dn, tn=0.0):
+        a, b = _f64(d0, self.n_dof), _f64(dn, self.n_dof)
+        _lib.check(self._lib.saa_set_state(self._h, _dptr(a), _dptr(b), float(tn)))
+
+    def get_state(self):
+        """Returns ``(d0, dn, tn)`` with the vectors shaped ``(3n,1)`` like the reference's."""
+        d0, dn, tn = np.empty(self.n_dof), np.empty(self.n_dof), C.c_double()
+        _lib.check(self._lib.saa_get_state(self._h, _dptr(d0), _dptr(dn), C.byref(tn)))
+        return d0.reshape(-1, 1), dn.reshape(-1, 1), tn.value
+
+    def get_state_device(self, d0_out=None, dn_out=None):
+        _lib.check(self._lib.saa_get_state_device(self._h, _dev(d0_out), _dev(dn_out)))
+
+    def set_loads(self, F_rankwise=None, l_M=None):
+        f = _f64(F_rankwise, self.n_dof) if F_rankwise is not None else None
+        m = _f64(l_M, self.n_dof) if l_M is not None else None
+        _lib.check(self._lib.saa_set_loads(self._h, _dptr(f) if f is not None else None,
+                                           _dptr(m) if m is not None else None))
+
+    # -- operators ------------------------------------------------------------------------------
+    def internal_force(self, d):
+        """``LocalK.dot(d)`` (``Dynamic_solver.py:12``), matrix-free on the GPU -> ``(3n,1)``."""
+        a, f = _f64(d, self.n_dof), np.empty(self.n_dof)
+        _lib.check(self._lib.saa_internal_force(self._h, _dptr(a), _dptr(f)))
+        return f.reshape(-1, 1)
+
+    def cd_update(self, f_int, d0, dn, tn):
+        a, b, c = _f64(f_int, self.n_dof), _f64(d0, self.n_dof), _f64(dn, self.n_dof)
+        out = np.empty(self.n_dof)
+        _lib.check(self._lib.saa_cd_update(self._h, _dptr(a), _dptr(b), _dptr(c), float(tn), _dptr(out)))
+        return out.reshape(-1, 1)
+
+    # -- stepping -------------------------------------------------------------------------------
+    def step(self, nsteps=1):
+        _lib.check(self._lib.saa_step(self._h, int(nsteps)))
+
+    def set_interface_buffer(self, iface):
+        """``iface``: float64 CUDA tensor of ``3*n_global_shared`` zeros, kept alive by the caller."""
+        if iface is not None and iface.numel() != 3 * self.n_global_shared:
+            raise ValueError("interface buffer must hold 3*n_global_shared doubles")
+        self._iface = iface
+        _lib.check(self._lib.saa_set_interface_buffer(self._h, _dev(iface)))
+
+    def step_begin(self):
+        _lib.check(self._lib.saa_step_begin(self._h))
+
+    def step_finish(self, hist=None, hist_row=0):
+        _lib.check(self._lib.saa_step_finish(self._h, _dev(hist), int(hist_row)))
+
+    def step_predicted(self, nsteps, table, table_row0=0, hist=None, hist_row0=0):
+        _lib.check(self._lib.saa_step_predicted(self._h, int(nsteps), _dev(table), int(table_row0),
+                                                _dev(hist), int(hist_row0)))
+
+    def halo_gather(self, row):
+        _lib.check(self._lib.saa_halo_gather(self._h, _dev(row)))
+
+    def halo_scatter(self, row):
+        _lib.check(self._lib.saa_halo_scatter(self._h, _dev(row)))
+
+    def time_steps(self, nsteps) -> float:
+        """Milliseconds (HIP events on the solver's stream) for ``nsteps`` exchange-free steps."""
+        ms = C.c_double()
+        _lib.check(self._lib.saa_time_steps(self._h, int(nsteps), C.byref(ms)))
+        return ms.value
+
+
+def plan_host_stats(points, cells, block_nodes=0) -> dict:
+    """Block-plan statistics without touching a GPU (``saa_plan_host_stats``)."""
+    lib = _lib.load()
+    pts, tets = _f64(points), _i32(cells)
+    st = _lib.PlanStats()
+    _lib.check(lib.saa_plan_host_stats(pts.size // 3, tets.size // 4, _dptr(pts), _iptr(tets),
+                                       int(block_nodes), C.byref(st)))
+    return st.as_dict()

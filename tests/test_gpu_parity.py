@@ -1,0 +1,140 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle and the reference's goldens.
+
+Tolerances (fp64): operator K.d rel-L2 < 1e-13; one update given the same f_int bit-exact;
+trajectories on beam_coarse inside the fp64 re-association noise envelope, with the stated parity
+bar rel-L2 < 1e-10 for steps <= 10 000."""
+import numpy as np
+import pytest
+
+from conftest import load_golden, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle():
+    from oracle import fem_oracle as fo
+    return fo
+
+
+def _serial_solver(mesh, E=1e6, nu=0.3, rho=1.0, fz=0.5, gamma=0.9, alpha=0.5, **kw):
+    """Serial problem in the reference's first-touch numbering, built with the product's host code."""
+    import synchronization_avoiding_algorithms_amd as saa
+    from synchronization_avoiding_algorithms_amd import fem_setup as fs
+    from synchronization_avoiding_algorithms_amd.mesh import clamp_nodes
+
+    lmd, mu = fs.lame(E, nu)
+    layouts, _ = fs.build_layouts(mesh.tets, np.zeros(len(mesh.tets), dtype=int), 1, len(mesh.points),
+                                  clamp_nodes(mesh))
+    lay = layouts[0]
+    lumped, fpre = fs.lumped_mass_and_load(mesh.points, mesh.tets, rho, fz)
+    dt = fs.cfl_dt(mesh.points, mesh.tets, E, nu, rho, gamma)
+    sol = saa.HipExplicitSolver(mesh.points[lay.nodes], lay.cells_local, lumped[lay.local_dof],
+                                fpre[lay.local_dof], lay.dirichlet_dofs, lmd, mu, dt, alpha, **kw)
+    return sol, lay, dt, lumped, fpre
+
+
+def noise_bound(step):
+    return {1: 1e-15, 10: 1e-14, 100: 1e-13, 1000: 5e-12, 5000: 5e-11}.get(step, 1e-10)
+
+
+def test_internal_force_matches_reference_spmv(beam_coarse):
+    g = load_golden("serial_setup.npz")
+    sol, lay, dt, _, _ = _serial_solver(beam_coarse)
+    assert np.array_equal(lay.nodes, g["local_nodes"])
+    assert dt == float(g["dt"])
+    f = sol.internal_force(g["d_rand"])
+    assert rel_l2(f, g["Kd_rand"]) < 1e-13
+    # linearity / null space: rigid translation produces no force
+    t = np.tile([1.0, -2.0, 0.5], sol.n_nodes)
+    assert np.abs(sol.internal_force(t)).max() < 1e-7 * np.abs(g["Kd_rand"]).max()
+    sol.close()
+
+
+def test_cd_update_bit_exact(beam_coarse):
+    fo = _oracle()
+    g = load_golden("serial_setup.npz")
+    sol, lay, dt, _, _ = _serial_solver(beam_coarse)
+    sol.set_loads(g["F_rankwise"], g["l_M"])  # the reference's own vectors (row-summed mass)
+    rng = np.random.default_rng(3)
+    n = sol.n_dof
+    f_int = rng.normal(size=(n, 1))
+    d0 = rng.normal(size=(n, 1)) * 1e-2
+    dn = rng.normal(size=(n, 1)) * 1e-2
+    for tn in (0.0, 0.37, 1.0, 2.5):
+        want = fo.cd_update(f_int, g["F_rankwise"], g["l_M"], d0, dn, np.float64(dt), tn, 0.5,
+                            g["local_dirichlet"])
+        got = sol.cd_update(f_int, d0, dn, tn)
+        assert np.array_equal(got, want), np.abs(got - want).max()
+    sol.close()
+
+
+def test_serial_trajectory_against_reference(beam_coarse):
+    g = load_golden("serial_trajectory.npz")
+    sol, lay, dt, _, _ = _serial_solver(beam_coarse)
+    done = 0
+    for s in (int(v) for v in g["steps"]):
+        sol.step(s - done)
+        done = s
+        d0, dn, tn = sol.get_state()
+        err = rel_l2(d0[:, 0], g[f"step_{s}"])
+        assert err < noise_bound(s), (s, err)
+    assert abs(tn - 10000 * dt) < 1e-9
+    sol.close()
+
+
+@pytest.mark.parametrize("n,block_nodes,threads", [(3, 0, 0), (4, 64, 128), (6, 200, 256), (6, 0, 1024)])
+def test_synthetic_beam_against_oracle(n, block_nodes, threads):
+    """Multi-block plans (halo nodes, duplicated border elements) on the synthetic cantilever."""
+    fo = _oracle()
+    from synchronization_avoiding_algorithms_amd.mesh import structured_beam
+
+    mesh = structured_beam(n)
+    sol, lay, dt, lumped, fpre = _serial_solver(mesh, block_nodes=block_nodes, threads=threads)
+    st = sol.plan_stats()
+    if block_nodes:
+        assert st["n_blocks"] > 1 and st["n_halo_total"] > 0
+    ranks, odt, _, _ = fo.setup_problem(mesh.points, mesh.tets, mesh.triangles, 1,
+                                        np.zeros(len(mesh.tets), dtype=int))
+    assert odt == dt
+    assert np.array_equal(ranks[0].nodes, lay.nodes)
+    assert rel_l2(lumped, fo.lumped_mass_and_load(mesh.tets, mesh.points, 1.0, 0.5)[0]) < 1e-14
+    rng = np.random.default_rng(n)
+    d = rng.uniform(-1e-2, 1e-2, size=(sol.n_dof, 1))
+    assert rel_l2(sol.internal_force(d), ranks[0].K.dot(d)) < 1e-13
+    # start from a rough state so that every dof moves from step 1 on
+    d0 = rng.uniform(-1e-4, 1e-4, size=(sol.n_dof, 1))
+    dn = d0 + rng.uniform(-1e-6, 1e-6, size=(sol.n_dof, 1))
+    d0[ranks[0].dirichlet] = 0
+    dn[ranks[0].dirichlet] = 0
+    sol.set_state(d0, dn, 0.25)
+    tn, o0, on = 0.25, d0, dn
+    for _ in range(200):
+        o1 = fo.explicit_step(ranks[0].K, ranks[0].F, ranks[0].dirichlet, tn, dt, o0, on, ranks[0].l_M, 0.5)
+        on, o0 = o0, o1
+        tn = tn + dt
+    sol.step(200)
+    g0, gn, gt = sol.get_state()
+    assert gt == tn
+    assert rel_l2(g0, o0) < 1e-11 and rel_l2(gn, on) < 1e-11
+    sol.close()
+
+
+def test_error_paths(beam_coarse):
+    import synchronization_avoiding_algorithms_amd as saa
+    from synchronization_avoiding_algorithms_amd._lib import SaaError
+
+    pts = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1.0]])
+    ones = np.ones(12)
+    with pytest.raises(SaaError):  # degenerate element
+        saa.HipExplicitSolver(pts * [1, 1, 0], [[0, 1, 2, 3]], ones, ones, [], 1.0, 1.0, 1e-3, 0.5)
+    with pytest.raises(SaaError):  # node id out of range
+        saa.HipExplicitSolver(pts, [[0, 1, 2, 4]], ones, ones, [], 1.0, 1.0, 1e-3, 0.5)
+    with pytest.raises(SaaError):  # zero mass
+        saa.HipExplicitSolver(pts, [[0, 1, 2, 3]], 0 * ones, ones, [], 1.0, 1.0, 1e-3, 0.5)
+    sol = saa.HipExplicitSolver(pts, [[0, 1, 2, 3]], ones, ones, [0, 1, 2], 1.0, 1.0, 1e-3, 0.5)
+    with pytest.raises(SaaError):
+        sol.step_finish()  # nothing in flight
+    sol.step(3)
+    d0, _, tn = sol.get_state()
+    assert not d0[:3].any() and np.isfinite(d0).all() and tn > 0
+    sol.close()
