@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""Headline benchmark: explicit linear-tet elastodynamics steps on synthetic cantilevers.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One *step* = one explicit time step of the whole mesh (fused HIP kernel per partition; for N > 1 a
+per-step all-reduce of the shared-node forces over RCCL).  N = 1 runs BASELINE.json configs[2]
+(the ~1M-tet beam, one partition); N > 1 keeps ~1M tets per GPU (weak scaling; N = 8 is configs[3],
+the ~8M-tet beam in 8 slabs).  Rank 0 prints ONE JSON line.
+
+Extra objects on the N = 1 line:
+  roofline      algorithmic bytes/step (16*Ne + 216*Nn) / HIP-event time of the fused
+                kernel's stream, against the 8 TB/s HBM peak of MI355X_MICROARCH.md.
+  cpu_baseline  the CPU oracle ("port": SciPy CSR K.dot + the NumPy update, the reference's own per-step
+                operations) timed on one host core on a bounded sample; the same sample is stepped on the GPU
+                and compared (parity.rel_l2).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+E, NU, RHO, FZ, ALPHA, GAMMA = 1e6, 0.3, 1.0, 0.5, 0.5, 0.9
+HBM_PEAK = 8.0e12  # B/s, MI355X_MICROARCH.md "HBM3E peak BW"
+# mesh refinement per GPU count: 150*n^3 tets ~ N * 1.03M
+N_FOR_GPUS = {1: 19, 2: 24, 3: 27, 4: 30, 5: 32, 6: 34, 7: 36, 8: 38}
+
+
+def build_rank_solver(mesh, n_parts, rank, device, block_nodes=0, threads=0):
+    import synchronization_avoiding_algorithms_amd as saa
+    from synchronization_avoiding_algorithms_amd import fem_setup as fs
+    from synchronization_avoiding_algorithms_amd.mesh import clamp_nodes, slab_partition
+
+    lmd, mu = fs.lame(E, NU)
+    epart = slab_partition(mesh, n_parts) if n_parts > 1 else np.zeros(len(mesh.tets), dtype=np.int64)
+    layouts, gshared = fs.build_layouts(mesh.tets, epart, n_parts, len(mesh.points), clamp_nodes(mesh))
+    lay = layouts[rank]
+    lumped, fpre = fs.lumped_mass_and_load(mesh.points, mesh.tets, RHO, FZ)
+    dt = fs.cfl_dt(mesh.points, mesh.tets, E, NU, RHO, GAMMA)  # == min over ranks of the local CFL steps
+    sol = saa.HipExplicitSolver(mesh.points[lay.nodes], lay.cells_local, lumped[lay.local_dof],
+                                fpre[lay.local_dof], lay.dirichlet_dofs, lmd, mu, dt, ALPHA,
+                                shared_local=lay.shared_local, shared_slots=lay.shared_slots,
+                                n_global_shared=len(gshared), device=device, block_nodes=block_nodes,
+                                threads=threads)
+    return sol, lay, gshared, dt
+
+
+def cpu_baseline_and_parity(sample_n=8, steps=300):
+    """Oracle (CPU port of the reference's per-step operations) timed on a bounded sample; the GPU steps the
+    same sample for the parity figure."""
+    from oracle import fem_oracle as fo
+    from synchronization_avoiding_algorithms_amd.mesh import structured_beam
+
+    mesh = structured_beam(sample_n)
+    ranks, dt, _, _ = fo.setup_problem(mesh.points, mesh.tets, mesh.triangles, 1,
+                                       np.zeros(len(mesh.tets), dtype=int))
+    rp = ranks[0]
+    d0 = np.zeros((len(rp.local_dof), 1))
+    dn = np.zeros_like(d0)
+    tn = 0
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        d1 = fo.explicit_step(rp.K, rp.F, rp.dirichlet, tn, dt, d0, dn, rp.l_M, ALPHA)
+        dn, d0 = d0, d1
+        tn = tn + dt
+    cpu_s = time.perf_counter() - t0
+    sol, lay, _, gdt = build_rank_solver(mesh, 1, 0, 0)
+    assert gdt == dt and np.array_equal(lay.nodes, rp.nodes)
+    sol.step(steps)
+    g0, _, _ = sol.get_state()
+    sol.close()
+    rel = float(np.linalg.norm(g0 - d0) / np.linalg.norm(d0))
+    ne = len(mesh.tets)
+    return ({"value": ne * steps / cpu_s, "unit": "element-updates/s", "cores": 1, "kind": "port",
+             "sample": f"synthetic beam n={sample_n} ({ne} tets, {len(mesh.points)} nodes), {steps} steps, "
+                       f"scipy CSR K.dot + numpy update (oracle/fem_oracle.py), {cpu_s:.2f} s"},
+            {"rel_l2": rel, "mesh": f"synthetic beam n={sample_n}", "steps": steps, "tolerance": 1e-10})
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5000)
+    ap.add_argument("--warmup", type=int, default=500)
+    ap.add_argument("--n", type=int, default=0, help="override mesh refinement (25n x n x n cubes)")
+    ap.add_argument("--block-nodes", type=int, default=0)
+    ap.add_argument("--threads", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from synchronization_avoiding_algorithms_amd.mesh import structured_beam
+
+    n = args.n or N_FOR_GPUS.get(world, int(round((world * 1028850 / 150.0) ** (1 / 3))))
+    mesh = structured_beam(n)
+    ne_total, nn_total = len(mesh.tets), len(mesh.points)
+    sol, lay, gshared, dt = build_rank_solver(mesh, world, rank, local_rank, args.block_nodes, args.threads)
+    stream = torch.cuda.current_stream()
+    sol.set_stream(stream.cuda_stream)
+    iface = torch.zeros(3 * len(gshared), dtype=torch.float64, device="cuda")
+    sol.set_interface_buffer(iface if world > 1 else None)
+
+    def run(k):
+        if world == 1:
+            sol.step(k)
+        else:
+            for _ in range(k):
+                sol.step_begin()
+                dist.all_reduce(iface)
+                sol.step_finish()
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    run(args.warmup)
+    fence()
+    t0 = time.perf_counter()
+    run(args.steps)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    out = None
+    if rank == 0:
+        stats = sol.plan_stats()
+        out = {
+            "metric": "element_updates_per_s", "value": ne_total * args.steps / elapsed,
+            "unit": "element-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "steps_per_s": args.steps / elapsed,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"synthetic 25n x n x n Kuhn-tet cantilever n={n}: {ne_total} tets, "
+                                   f"{nn_total} nodes, {world} x-slab partition(s), fp64, E=1e6 nu=0.3 "
+                                   f"alpha=0.5 ramped body force, dt={dt:.6e}",
+                       "exchange": "none (1 partition)" if world == 1 else
+                                   f"RCCL all-reduce of {3 * len(gshared)} fp64 shared-node forces every step",
+                       "plan": stats},
+        }
+    if world == 1:
+        # roofline of the dominant (only) kernel: HIP events on the kernel's own stream
+        k = max(200, min(args.steps, 2000))
+        ms = sol.time_steps(k)
+        b_alg = 16 * ne_total + 216 * nn_total
+        achieved = b_alg * k / (ms * 1e-3)
+        out["roofline"] = {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                           "frac": achieved / HBM_PEAK, "traffic": None,
+                           "kernel": "fused_step_kernel<false>", "avg_launch_us": 1e3 * ms / k,
+                           "algorithmic_bytes_per_launch": b_alg,
+                           "algorithmic_bytes_per_element_update": b_alg / ne_total}
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"], out["parity"] = cpu_baseline_and_parity()
+    sol.close()
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

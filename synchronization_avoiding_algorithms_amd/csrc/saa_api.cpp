@@ -535,4 +535,27 @@ int saa_time_steps(saa_solver *s, int32_t nsteps, double *elapsed_ms) {
   return rc;
 }
 
+// Diagnostic, not part of include/saa_hip.h: time `nsteps` launches of an ablated step kernel
+// (state is not rotated; outputs are meaningless).  Used by tools/ablate.py only.
+int saa_debug_time_ablated(saa_solver *s, int32_t variant, int32_t nsteps, double *elapsed_ms) {
+  if (!s || !elapsed_ms) return fail(SAA_E_ARG, "saa_debug_time_ablated: bad argument");
+  HIP_TRY(hipSetDevice(s->device));
+  hipEvent_t a, b;
+  HIP_TRY(hipEventCreate(&a));
+  HIP_TRY(hipEventCreate(&b));
+  s->set_ramp();
+  HIP_TRY(hipEventRecord(a, s->stream));
+  for (int32_t k = 0; k < nsteps; ++k)
+    saa::launch_fused_step_ablated(variant, s->mesh, s->threads, s->lds_bytes, s->stream, s->dbuf[s->i0].p,
+                                   s->dbuf[s->in_].p, s->dbuf[s->i1].p, s->consts);
+  HIP_TRY(hipEventRecord(b, s->stream));
+  HIP_TRY(hipEventSynchronize(b));
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, a, b));
+  *elapsed_ms = ms;
+  (void)hipEventDestroy(a);
+  (void)hipEventDestroy(b);
+  return check_launch();
+}
+
 }  // extern "C"

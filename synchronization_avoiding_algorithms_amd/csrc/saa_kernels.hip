@@ -99,10 +99,12 @@ __device__ __forceinline__ int plan_block(int bid, int n_blocks) {
   return x * per + (x < rem ? x : rem) + j;
 }
 
-template <bool FORCE_ONLY>
+// ABLATE (diagnostic builds only, never launched by the product path): 1 = no LDS atomics,
+// 2 = no LDS record reads, 3 = no staging loads, 4 = no update phase, 5 = no element phase.
+template <bool FORCE_ONLY, int ABLATE = 0>
 __global__ void fused_step_kernel(DeviceMesh m, const double *__restrict__ d0, const double *__restrict__ dn,
                                   double *__restrict__ out, double *__restrict__ iface, StepConsts k) {
-  extern __shared__ double lds[];
+  extern __shared__ __attribute__((aligned(16))) double lds[];
   const BlockDesc bd = m.blocks[plan_block(blockIdx.x, m.n_blocks)];
   const int tid = threadIdx.x, nt = blockDim.x;
   const int n_loc = bd.n_owned + bd.n_halo;
@@ -115,16 +117,16 @@ __global__ void fused_step_kernel(DeviceMesh m, const double *__restrict__ d0, c
     const double *uo = d0 + 3 * (int64_t)bd.node_start;
     for (int i = tid; i < 3 * bd.n_owned; i += nt) {
       const int n = i / 3, c = i - 3 * n;
-      rec[6 * n + c] = xo[i];
-      rec[6 * n + 3 + c] = uo[i];
+      rec[6 * n + c] = ABLATE == 3 ? 1.0 * i : xo[i];
+      rec[6 * n + 3 + c] = ABLATE == 3 ? 1e-3 * i : uo[i];
       acc[i] = 0.0;
     }
     const int32_t *hid = m.halo_ids + bd.halo_off;
     for (int i = tid; i < 3 * bd.n_halo; i += nt) {
       const int n = i / 3, c = i - 3 * n;
-      const int64_t g = 3 * (int64_t)hid[n] + c;
-      rec[6 * (bd.n_owned + n) + c] = m.xyz[g];
-      rec[6 * (bd.n_owned + n) + 3 + c] = d0[g];
+      const int64_t g = ABLATE == 3 ? i : 3 * (int64_t)hid[n] + c;
+      rec[6 * (bd.n_owned + n) + c] = ABLATE == 3 ? 2.0 * i : m.xyz[g];
+      rec[6 * (bd.n_owned + n) + 3 + c] = ABLATE == 3 ? 1e-3 * i : d0[g];
     }
   }
   __syncthreads();
@@ -133,13 +135,27 @@ __global__ void fused_step_kernel(DeviceMesh m, const double *__restrict__ d0, c
   {
     const ushort4 *conn = m.conn + bd.elem_off;
     const int n_owned = bd.n_owned;
-    for (int e = tid; e < bd.n_elem; e += nt) {
+    double sink = 0.0;
+    for (int e = tid; e < (ABLATE == 5 ? 0 : bd.n_elem); e += nt) {
       const ushort4 c = conn[e];
-      const double *r0 = rec + 6 * c.x, *r1 = rec + 6 * c.y, *r2 = rec + 6 * c.z, *r3 = rec + 6 * c.w;
+      // 48-byte records, 16-byte aligned: three ds_read_b128 per node
+      const double2 *r0 = reinterpret_cast<const double2 *>(rec + 6 * c.x);
+      const double2 *r1 = reinterpret_cast<const double2 *>(rec + 6 * c.y);
+      const double2 *r2 = reinterpret_cast<const double2 *>(rec + 6 * c.z);
+      const double2 *r3 = reinterpret_cast<const double2 *>(rec + 6 * c.w);
+      if (ABLATE == 2) {  // every lane reads its own fixed record: no index-dependent LDS traffic
+        r0 = reinterpret_cast<const double2 *>(rec + 6 * (tid & 63)); r1 = r0 + 3; r2 = r0 + 6; r3 = r0 + 9;
+      }
+      const double2 a0 = r0[0], b0 = r0[1], c0 = r0[2], a1 = r1[0], b1 = r1[1], c1 = r1[2];
+      const double2 a2 = r2[0], b2 = r2[1], c2 = r2[2], a3 = r3[0], b3 = r3[1], c3 = r3[2];
       Vec3 f1, f2, f3;
-      tet_forces({r0[0], r0[1], r0[2]}, {r1[0], r1[1], r1[2]}, {r2[0], r2[1], r2[2]}, {r3[0], r3[1], r3[2]},
-                 {r0[3], r0[4], r0[5]}, {r1[3], r1[4], r1[5]}, {r2[3], r2[4], r2[5]}, {r3[3], r3[4], r3[5]},
+      tet_forces({a0.x, a0.y, b0.x}, {a1.x, a1.y, b1.x}, {a2.x, a2.y, b2.x}, {a3.x, a3.y, b3.x},
+                 {b0.y, c0.x, c0.y}, {b1.y, c1.x, c1.y}, {b2.y, c2.x, c2.y}, {b3.y, c3.x, c3.y},
                  m.lambda_, m.mu, f1, f2, f3);
+      if (ABLATE == 1) {
+        sink += f1.x + f1.y + f1.z + f2.x + f2.y + f2.z + f3.x + f3.y + f3.z;
+        continue;
+      }
       if (c.x < n_owned) {
         lds_add(acc + 3 * c.x + 0, -(f1.x + f2.x + f3.x));
         lds_add(acc + 3 * c.x + 1, -(f1.y + f2.y + f3.y));
@@ -161,8 +177,13 @@ __global__ void fused_step_kernel(DeviceMesh m, const double *__restrict__ d0, c
         lds_add(acc + 3 * c.w + 2, f3.z);
       }
     }
+    if (ABLATE == 1 && sink == 12345.678) acc[0] = sink;
   }
   __syncthreads();
+  if (ABLATE == 4) {
+    if (tid == 0) out[3 * (int64_t)bd.node_start] = acc[0];
+    return;
+  }
 
   // ---- 3. owned dofs: write f_int, or update -------------------------------------------------
   {
@@ -264,6 +285,24 @@ void launch_fused_step(const DeviceMesh &m, int threads, int lds_bytes, hipStrea
                        const double *dn, double *d1, double *iface, const StepConsts &k) {
   hipLaunchKernelGGL(fused_step_kernel<false>, dim3(m.n_blocks), dim3(threads), lds_bytes, st, m, d0, dn, d1,
                      iface, k);
+}
+
+// Diagnostic only (tools/ablate.py): the step kernel with one phase removed; results are garbage.
+void launch_fused_step_ablated(int variant, const DeviceMesh &m, int threads, int lds_bytes, hipStream_t st,
+                               const double *d0, const double *dn, double *d1, const StepConsts &k) {
+  double *none = nullptr;
+#define SAA_ABL(V)                                                                                         \
+  case V:                                                                                                  \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_step_kernel<false, V>),                \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);                      \
+    hipLaunchKernelGGL((fused_step_kernel<false, V>), dim3(m.n_blocks), dim3(threads), lds_bytes, st, m, d0, \
+                       dn, d1, none, k);                                                                   \
+    break;
+  switch (variant) {
+    SAA_ABL(0) SAA_ABL(1) SAA_ABL(2) SAA_ABL(3) SAA_ABL(4) SAA_ABL(5)
+    default: break;
+  }
+#undef SAA_ABL
 }
 
 void launch_force_only(const DeviceMesh &m, int threads, int lds_bytes, hipStream_t st, const double *d,

@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Diagnostic: time the fused step kernel with one phase removed (see ABLATE in saa_kernels.hip)."""
+import ctypes as C
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+
+from bench import build_rank_solver  # noqa: E402
+from synchronization_avoiding_algorithms_amd import _lib  # noqa: E402
+from synchronization_avoiding_algorithms_amd.mesh import structured_beam  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 19
+bn = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+th = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+mesh = structured_beam(n)
+sol, lay, _, dt = build_rank_solver(mesh, 1, 0, 0, bn, th)
+rng = np.random.default_rng(0)
+d = rng.uniform(-1e-4, 1e-4, size=sol.n_dof)
+sol.set_state(d, d, 0.5)
+lib = _lib.load()
+lib.saa_debug_time_ablated.restype = C.c_int
+lib.saa_debug_time_ablated.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_double)]
+names = {0: "full", 1: "no LDS atomics", 2: "no indexed LDS reads", 3: "no staging loads",
+         4: "no update phase", 5: "no element phase"}
+print("plan", sol.plan_stats())
+ms = C.c_double()
+for v in (0, 1, 2, 3, 4, 5, 0):
+    lib.saa_debug_time_ablated(sol._h, v, 200, C.byref(ms))
+    lib.saa_debug_time_ablated(sol._h, v, 1000, C.byref(ms))
+    print(f"variant {v} ({names[v]:22s}): {ms.value:8.3f} us/launch")
