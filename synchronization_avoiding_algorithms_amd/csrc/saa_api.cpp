@@ -290,9 +290,16 @@ int saa_create(const saa_problem *pb, saa_solver **out) {
   for (int32_t g = 0; g < pb->n_global_shared; ++g)
     if (!local_slot[g]) foreign.push_back(g);
 
+  {
+    // one entry of padding: the kernel's clamped prefetches read index 0 of possibly empty lists
+    std::vector<int32_t> halo_padded(plan.halo_ids);
+    halo_padded.push_back(0);
+    std::vector<uint16_t> conn_padded(plan.conn);
+    conn_padded.insert(conn_padded.end(), 4, 0);
+    CREATE_TRY(s->halo_ids.upload(halo_padded));
+    CREATE_TRY(s->conn.upload(conn_padded));
+  }
   CREATE_TRY(s->blocks.upload(plan.blocks));
-  CREATE_TRY(s->halo_ids.upload(plan.halo_ids));
-  CREATE_TRY(s->conn.upload(plan.conn));
   CREATE_TRY(s->new_to_old.upload(plan.new_to_old));
   CREATE_TRY(s->xyz.upload(xyz));
   CREATE_TRY(s->mass.upload(mass));

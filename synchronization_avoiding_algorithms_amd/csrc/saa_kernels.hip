@@ -99,109 +99,189 @@ __device__ __forceinline__ int plan_block(int bid, int n_blocks) {
   return x * per + (x < rem ? x : rem) + j;
 }
 
+// Workgroup barrier that orders LDS traffic only: unlike __syncthreads() it does not drain the
+// global loads this kernel deliberately keeps in flight across its phases.
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+// One element: read its 4 node records (48 B, 16-B aligned -> three ds_read_b128 each), evaluate the
+// nodal forces and add those of OWNED nodes to the block's accumulators.
+template <int ABLATE>
+__device__ __forceinline__ void element_forces(const ushort4 c, const double *rec, double *acc, int n_owned,
+                                               double lam, double mu, int tid, double &sink) {
+  const double2 *r0 = reinterpret_cast<const double2 *>(rec + 6 * c.x);
+  const double2 *r1 = reinterpret_cast<const double2 *>(rec + 6 * c.y);
+  const double2 *r2 = reinterpret_cast<const double2 *>(rec + 6 * c.z);
+  const double2 *r3 = reinterpret_cast<const double2 *>(rec + 6 * c.w);
+  if (ABLATE == 2) {  // every lane reads its own fixed record: no index-dependent LDS traffic
+    r0 = reinterpret_cast<const double2 *>(rec + 6 * (tid & 63)); r1 = r0 + 3; r2 = r0 + 6; r3 = r0 + 9;
+  }
+  const double2 a0 = r0[0], b0 = r0[1], c0 = r0[2], a1 = r1[0], b1 = r1[1], c1 = r1[2];
+  const double2 a2 = r2[0], b2 = r2[1], c2 = r2[2], a3 = r3[0], b3 = r3[1], c3 = r3[2];
+  Vec3 f1, f2, f3;
+  tet_forces({a0.x, a0.y, b0.x}, {a1.x, a1.y, b1.x}, {a2.x, a2.y, b2.x}, {a3.x, a3.y, b3.x},
+             {b0.y, c0.x, c0.y}, {b1.y, c1.x, c1.y}, {b2.y, c2.x, c2.y}, {b3.y, c3.x, c3.y}, lam, mu, f1, f2, f3);
+  if (ABLATE == 1) {
+    sink += f1.x + f1.y + f1.z + f2.x + f2.y + f2.z + f3.x + f3.y + f3.z;
+    return;
+  }
+  if (c.x < n_owned) {
+    lds_add(acc + 3 * c.x + 0, -(f1.x + f2.x + f3.x));
+    lds_add(acc + 3 * c.x + 1, -(f1.y + f2.y + f3.y));
+    lds_add(acc + 3 * c.x + 2, -(f1.z + f2.z + f3.z));
+  }
+  if (c.y < n_owned) {
+    lds_add(acc + 3 * c.y + 0, f1.x);
+    lds_add(acc + 3 * c.y + 1, f1.y);
+    lds_add(acc + 3 * c.y + 2, f1.z);
+  }
+  if (c.z < n_owned) {
+    lds_add(acc + 3 * c.z + 0, f2.x);
+    lds_add(acc + 3 * c.z + 1, f2.y);
+    lds_add(acc + 3 * c.z + 2, f2.z);
+  }
+  if (c.w < n_owned) {
+    lds_add(acc + 3 * c.w + 0, f3.x);
+    lds_add(acc + 3 * c.w + 1, f3.y);
+    lds_add(acc + 3 * c.w + 2, f3.z);
+  }
+}
+
+// Per-thread prefetch depth (dofs): the update operands of the first kPreOwn*blockDim owned dofs and
+// the records of the first kPreHalo*blockDim halo dofs travel in registers while elements are computed.
+constexpr int kPreOwn = 3;
+constexpr int kPreHalo = 2;
+// Connectivity of the first kPreConn interior sweeps is fetched BEFORE those loads: vector-memory
+// results return in issue order, so a connectivity load issued later would make the first interior
+// element wait for every prefetch in front of it.
+constexpr int kPreConn = 4;
+
 // ABLATE (diagnostic builds only, never launched by the product path): 1 = no LDS atomics,
-// 2 = no LDS record reads, 3 = no staging loads, 4 = no update phase, 5 = no element phase.
+// 2 = no indexed LDS reads, 3 = no staging loads, 4 = no update phase, 5 = no element phase.
 template <bool FORCE_ONLY, int ABLATE = 0>
 __global__ void fused_step_kernel(DeviceMesh m, const double *__restrict__ d0, const double *__restrict__ dn,
                                   double *__restrict__ out, double *__restrict__ iface, StepConsts k) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const BlockDesc bd = m.blocks[plan_block(blockIdx.x, m.n_blocks)];
   const int tid = threadIdx.x, nt = blockDim.x;
-  const int n_loc = bd.n_owned + bd.n_halo;
-  double *rec = lds;                     // [n_loc][6]: x y z ux uy uz
+  double *rec = lds;                     // [n_owned + n_halo][6]: x y z ux uy uz
   double *acc = lds + 6 * m.max_local;   // [n_owned][3]
+  const int n_own3 = 3 * bd.n_owned, n_halo3 = 3 * bd.n_halo;
+  const int64_t base = 3 * (int64_t)bd.node_start;
+  const int32_t *hid = m.halo_ids + bd.halo_off;
 
-  // ---- 1. stage owned (contiguous) and halo (indexed) node records ---------------------------
+  // ---- 0. interior connectivity and halo ids first (see kPreConn) ------------------------------
+  const ushort4 *conn = m.conn + bd.elem_off;
+  ushort4 cpre[kPreConn];
+#pragma unroll
+  // All prefetch loads are UNCONDITIONAL with clamped (always valid) indices: loads under a
+  // divergent branch make hipcc fall back to s_waitcnt vmcnt(0) at the first use (the plan pads
+  // conn / halo_ids by one entry so that index 0 exists even for an empty list).
+  for (int j = 0; j < kPreConn; ++j) cpre[j] = conn[min(tid + j * nt, max(bd.n_elem - 1, 0))];
+  int64_t hg[kPreHalo];
+#pragma unroll
+  for (int j = 0; j < kPreHalo; ++j) {
+    const int i = min(tid + j * nt, max(n_halo3 - 1, 0));
+    const int n = i / 3;
+    hg[j] = 3 * (int64_t)hid[n] + (i - 3 * n);
+  }
+
+  // ---- 1. owned node records (contiguous) -> LDS; zero the accumulators -------------------------
   {
-    const double *xo = m.xyz + 3 * (int64_t)bd.node_start;
-    const double *uo = d0 + 3 * (int64_t)bd.node_start;
-    for (int i = tid; i < 3 * bd.n_owned; i += nt) {
+    const double *xo = m.xyz + base;
+    const double *uo = d0 + base;
+    for (int i = tid; i < n_own3; i += nt) {
       const int n = i / 3, c = i - 3 * n;
       rec[6 * n + c] = ABLATE == 3 ? 1.0 * i : xo[i];
       rec[6 * n + 3 + c] = ABLATE == 3 ? 1e-3 * i : uo[i];
       acc[i] = 0.0;
     }
-    const int32_t *hid = m.halo_ids + bd.halo_off;
-    for (int i = tid; i < 3 * bd.n_halo; i += nt) {
-      const int n = i / 3, c = i - 3 * n;
-      const int64_t g = ABLATE == 3 ? i : 3 * (int64_t)hid[n] + c;
-      rec[6 * (bd.n_owned + n) + c] = ABLATE == 3 ? 2.0 * i : m.xyz[g];
-      rec[6 * (bd.n_owned + n) + 3 + c] = ABLATE == 3 ? 1e-3 * i : d0[g];
-    }
   }
-  __syncthreads();
 
-  // ---- 2. elements: one per lane, accumulate owned-node forces in LDS ------------------------
-  {
-    const ushort4 *conn = m.conn + bd.elem_off;
-    const int n_owned = bd.n_owned;
-    double sink = 0.0;
-    for (int e = tid; e < (ABLATE == 5 ? 0 : bd.n_elem); e += nt) {
-      const ushort4 c = conn[e];
-      // 48-byte records, 16-byte aligned: three ds_read_b128 per node
-      const double2 *r0 = reinterpret_cast<const double2 *>(rec + 6 * c.x);
-      const double2 *r1 = reinterpret_cast<const double2 *>(rec + 6 * c.y);
-      const double2 *r2 = reinterpret_cast<const double2 *>(rec + 6 * c.z);
-      const double2 *r3 = reinterpret_cast<const double2 *>(rec + 6 * c.w);
-      if (ABLATE == 2) {  // every lane reads its own fixed record: no index-dependent LDS traffic
-        r0 = reinterpret_cast<const double2 *>(rec + 6 * (tid & 63)); r1 = r0 + 3; r2 = r0 + 6; r3 = r0 + 9;
-      }
-      const double2 a0 = r0[0], b0 = r0[1], c0 = r0[2], a1 = r1[0], b1 = r1[1], c1 = r1[2];
-      const double2 a2 = r2[0], b2 = r2[1], c2 = r2[2], a3 = r3[0], b3 = r3[1], c3 = r3[2];
-      Vec3 f1, f2, f3;
-      tet_forces({a0.x, a0.y, b0.x}, {a1.x, a1.y, b1.x}, {a2.x, a2.y, b2.x}, {a3.x, a3.y, b3.x},
-                 {b0.y, c0.x, c0.y}, {b1.y, c1.x, c1.y}, {b2.y, c2.x, c2.y}, {b3.y, c3.x, c3.y},
-                 m.lambda_, m.mu, f1, f2, f3);
-      if (ABLATE == 1) {
-        sink += f1.x + f1.y + f1.z + f2.x + f2.y + f2.z + f3.x + f3.y + f3.z;
-        continue;
-      }
-      if (c.x < n_owned) {
-        lds_add(acc + 3 * c.x + 0, -(f1.x + f2.x + f3.x));
-        lds_add(acc + 3 * c.x + 1, -(f1.y + f2.y + f3.y));
-        lds_add(acc + 3 * c.x + 2, -(f1.z + f2.z + f3.z));
-      }
-      if (c.y < n_owned) {
-        lds_add(acc + 3 * c.y + 0, f1.x);
-        lds_add(acc + 3 * c.y + 1, f1.y);
-        lds_add(acc + 3 * c.y + 2, f1.z);
-      }
-      if (c.z < n_owned) {
-        lds_add(acc + 3 * c.z + 0, f2.x);
-        lds_add(acc + 3 * c.z + 1, f2.y);
-        lds_add(acc + 3 * c.z + 2, f2.z);
-      }
-      if (c.w < n_owned) {
-        lds_add(acc + 3 * c.w + 0, f3.x);
-        lds_add(acc + 3 * c.w + 1, f3.y);
-        lds_add(acc + 3 * c.w + 2, f3.z);
-      }
-    }
-    if (ABLATE == 1 && sink == 12345.678) acc[0] = sink;
+  // ---- 2. issue the loads whose latency hides under the interior elements ---------------------
+  double hx[kPreHalo], hu[kPreHalo];
+#pragma unroll
+  for (int j = 0; j < kPreHalo; ++j) {
+    hx[j] = ABLATE == 3 ? 1.0 * tid : m.xyz[hg[j]];
+    hu[j] = ABLATE == 3 ? 1e-3 * tid : d0[hg[j]];
   }
-  __syncthreads();
+  double pm[kPreOwn], pf[kPreOwn], pn[kPreOwn];
+  int32_t ptag[kPreOwn];
+  if (!FORCE_ONLY) {
+#pragma unroll
+    for (int j = 0; j < kPreOwn; ++j) {
+      const int i = min(tid + j * nt, n_own3 - 1);
+      pm[j] = ABLATE == 4 ? 1.0 : m.mass[base + i];
+      pf[j] = ABLATE == 4 ? 0.0 : m.fext[base + i];
+      pn[j] = ABLATE == 4 ? 0.0 : dn[base + i];
+      ptag[j] = ABLATE == 4 ? 0 : m.tag[bd.node_start + i / 3];
+    }
+  }
+  lds_barrier();
+
+  // ---- 3. interior elements (all four nodes owned) --------------------------------------------
+  double sink = 0.0;
+  if (ABLATE != 5) {
+#pragma unroll
+    for (int j = 0; j < kPreConn; ++j)
+      if (tid + j * nt < bd.n_interior)
+        element_forces<ABLATE>(cpre[j], rec, acc, bd.n_owned, m.lambda_, m.mu, tid, sink);
+    for (int e = tid + kPreConn * nt; e < bd.n_interior; e += nt)
+      element_forces<ABLATE>(conn[e], rec, acc, bd.n_owned, m.lambda_, m.mu, tid, sink);
+  }
+
+  // ---- 4. halo records -> LDS --------------------------------------------------------------------
+#pragma unroll
+  for (int j = 0; j < kPreHalo; ++j) {
+    const int i = tid + j * nt;
+    if (i < n_halo3) {
+      const int n = i / 3, c = i - 3 * n;
+      rec[6 * (bd.n_owned + n) + c] = hx[j];
+      rec[6 * (bd.n_owned + n) + 3 + c] = hu[j];
+    }
+  }
+  for (int i = tid + kPreHalo * nt; i < n_halo3; i += nt) {  // blocks with more halo than the prefetch depth
+    const int n = i / 3, c = i - 3 * n;
+    const int64_t g = 3 * (int64_t)hid[n] + c;
+    rec[6 * (bd.n_owned + n) + c] = m.xyz[g];
+    rec[6 * (bd.n_owned + n) + 3 + c] = d0[g];
+  }
+  lds_barrier();
+
+  // ---- 5. boundary elements (at least one halo node) ----------------------------------------------
+  if (ABLATE != 5)
+    for (int e = bd.n_interior + tid; e < bd.n_elem; e += nt)
+      element_forces<ABLATE>(conn[e], rec, acc, bd.n_owned, m.lambda_, m.mu, tid, sink);
+  if (ABLATE == 1 && sink == 12345.678) acc[0] = sink;
+  lds_barrier();
   if (ABLATE == 4) {
-    if (tid == 0) out[3 * (int64_t)bd.node_start] = acc[0];
+    if (tid == 0) out[base] = acc[0];
     return;
   }
 
-  // ---- 3. owned dofs: write f_int, or update -------------------------------------------------
-  {
-    const int64_t base = 3 * (int64_t)bd.node_start;
-    for (int i = tid; i < 3 * bd.n_owned; i += nt) {
-      const double f = acc[i];
-      if (FORCE_ONLY) {
-        out[base + i] = f;
-      } else {
-        const int n = i / 3, c = i - 3 * n;
-        const int32_t tag = m.tag[bd.node_start + n];
-        if (iface != nullptr && (tag & kTagShared)) iface[3 * (int64_t)(tag >> kTagSlotShift) + c] = f;
-        double v = cd_update_dof(f, m.fext[base + i], m.mass[base + i], rec[6 * n + 3 + c], dn[base + i], k);
-        if (tag & (1 << c)) v = 0.0;  // d1[Local_Dirichlet] = 0   (Dynamic_solver.py:20)
-        out[base + i] = v;
-      }
-    }
+  // ---- 6. owned dofs: write f_int, or update --------------------------------------------------------
+  if (FORCE_ONLY) {
+    for (int i = tid; i < n_own3; i += nt) out[base + i] = acc[i];
+    return;
   }
+  auto finish = [&](int i, double mass, double fpre, double dnv, int32_t tag) {
+    const int n = i / 3, c = i - 3 * n;
+    const double f = acc[i];
+    if (iface != nullptr && (tag & kTagShared)) iface[3 * (int64_t)(tag >> kTagSlotShift) + c] = f;
+    double v = cd_update_dof(f, fpre, mass, rec[6 * n + 3 + c], dnv, k);
+    if (tag & (1 << c)) v = 0.0;  // d1[Local_Dirichlet] = 0   (Dynamic_solver.py:20)
+    out[base + i] = v;
+  };
+#pragma unroll
+  for (int j = 0; j < kPreOwn; ++j) {
+    const int i = tid + j * nt;
+    if (i < n_own3) finish(i, pm[j], pf[j], pn[j], ptag[j]);
+  }
+  for (int i = tid + kPreOwn * nt; i < n_own3; i += nt)
+    finish(i, m.mass[base + i], m.fext[base + i], dn[base + i], m.tag[bd.node_start + i / 3]);
 }
 
 template __global__ void fused_step_kernel<false>(DeviceMesh, const double *, const double *, double *,

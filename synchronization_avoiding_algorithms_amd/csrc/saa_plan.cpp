@@ -170,6 +170,7 @@ bool build_once(int32_t n_nodes, int32_t n_elems, const double *xyz, const int32
   plan.conn.resize(4 * static_cast<size_t>(plan.n_elem_copies));
   std::vector<int32_t> tmp;
   std::vector<uint16_t> reorder_scratch;
+  std::vector<char> interior_flag;
   for (int32_t b = 0; b < n_blocks; ++b) {
     BlockDesc &d = plan.blocks[b];
     d.node_start = block_start[b];
@@ -201,7 +202,31 @@ bool build_once(int32_t n_nodes, int32_t n_elems, const double *xyz, const int32
           loc = d.n_owned + static_cast<int32_t>(std::lower_bound(tmp.begin(), tmp.end(), g) - tmp.begin());
         plan.conn[4 * static_cast<size_t>(c) + a] = static_cast<uint16_t>(loc);
       }
-    reorder_for_atomics(plan.conn, off[b], d.n_elem, d.n_owned, reorder_scratch);
+    // interior elements first (they can run before the halo records have arrived), then each part
+    // gets its own conflict-avoiding order
+    {
+      uint16_t *cb = &plan.conn[4 * static_cast<size_t>(off[b])];
+      reorder_scratch.assign(cb, cb + 4 * static_cast<size_t>(d.n_elem));
+      int32_t lo_i = 0, hi_i = d.n_elem;
+      for (int32_t e = 0; e < d.n_elem; ++e) {
+        const uint16_t *c = &reorder_scratch[4 * static_cast<size_t>(e)];
+        const bool interior = c[0] < d.n_owned && c[1] < d.n_owned && c[2] < d.n_owned && c[3] < d.n_owned;
+        interior_flag.push_back(interior);
+        if (interior) ++lo_i;
+      }
+      d.n_interior = lo_i;
+      int32_t wi = 0, wb = lo_i;
+      for (int32_t e = 0; e < d.n_elem; ++e) {
+        const int32_t dst = interior_flag[e] ? wi++ : wb++;
+        std::copy(&reorder_scratch[4 * static_cast<size_t>(e)], &reorder_scratch[4 * static_cast<size_t>(e)] + 4,
+                  cb + 4 * static_cast<size_t>(dst));
+      }
+      (void)hi_i;
+      interior_flag.clear();
+    }
+    d.pad_ = 0;
+    reorder_for_atomics(plan.conn, off[b], d.n_interior, d.n_owned, reorder_scratch);
+    reorder_for_atomics(plan.conn, off[b] + d.n_interior, d.n_elem - d.n_interior, d.n_owned, reorder_scratch);
     plan.halo_ids.insert(plan.halo_ids.end(), tmp.begin(), tmp.end());
     plan.max_owned = std::max(plan.max_owned, d.n_owned);
     plan.max_local = std::max(plan.max_local, d.n_owned + d.n_halo);

@@ -20,6 +20,8 @@ struct BlockDesc {
   int32_t n_halo;
   int32_t elem_off;    // offset into conn (element copies)
   int32_t n_elem;
+  int32_t n_interior;  // elements [0,n_interior) touch owned nodes only; the rest need halo records
+  int32_t pad_;
 };
 
 struct Plan {
