@@ -76,6 +76,7 @@ typedef struct saa_plan_stats {
   int64_t n_halo_total;     /* sum over blocks of halo nodes */
   int32_t lds_bytes;        /* dynamic LDS per workgroup */
   int32_t threads;          /* workgroup size in use */
+  double lds_conflict_factor; /* mean worst LDS bank multiplicity per (half-wave, vertex slot); 1 = none */
 } saa_plan_stats;
 
 const char *saa_last_error(void);

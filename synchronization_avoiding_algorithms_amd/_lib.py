@@ -42,11 +42,12 @@ class PlanStats(C.Structure):
     _fields_ = [
         ("n_blocks", C.c_int32), ("max_owned", C.c_int32), ("max_local", C.c_int32),
         ("n_elem_copies", C.c_int64), ("n_halo_total", C.c_int64),
-        ("lds_bytes", C.c_int32), ("threads", C.c_int32),
+        ("lds_bytes", C.c_int32), ("threads", C.c_int32), ("lds_conflict_factor", C.c_double),
     ]
 
     def as_dict(self):
-        return {name: int(getattr(self, name)) for name, _ in self._fields_}
+        return {name: (float if name == "lds_conflict_factor" else int)(getattr(self, name))
+                for name, _ in self._fields_}
 
 
 _dp = C.POINTER(C.c_double)

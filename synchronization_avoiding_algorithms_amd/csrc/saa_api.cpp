@@ -103,7 +103,7 @@ int pick_threads(const saa::Plan &plan, int requested) {
   return 64;
 }
 
-int lds_bytes_of(const saa::Plan &plan) { return 8 * (6 * plan.max_local + 3 * plan.max_owned); }
+int lds_bytes_of(const saa::Plan &plan) { return saa::lds_bytes_for(plan.max_local); }
 
 void fill_stats(const saa::Plan &plan, int lds, int threads, saa_plan_stats *out) {
   out->n_blocks = static_cast<int32_t>(plan.blocks.size());
@@ -113,6 +113,7 @@ void fill_stats(const saa::Plan &plan, int lds, int threads, saa_plan_stats *out
   out->n_halo_total = plan.n_halo_total;
   out->lds_bytes = lds;
   out->threads = threads;
+  out->lds_conflict_factor = plan.lds_conflict_factor;
 }
 
 bool build_fitting_plan(int32_t n_nodes, int32_t n_elems, const double *xyz, const int32_t *tets,

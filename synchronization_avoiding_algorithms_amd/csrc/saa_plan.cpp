@@ -2,6 +2,8 @@
 #include "saa_plan.h"
 
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <cmath>
 #include <numeric>
 
@@ -45,57 +47,114 @@ struct Rcb {
   }
 };
 
-// Re-order the element copies of one block for the LDS atomics of the element phase.
-// A ds_add_f64 wave-instruction is executed per (vertex slot, component) over two 32-lane halves;
-// lanes of a half whose accumulators share an LDS bank pair (8-byte words: (3*node+c) mod 32, i.e.
-// node mod 32 for a fixed component) are serialised, lanes on the SAME address even more so
-// (measured on gfx950, tools/lds_microbench.hip: 7 cycles per wave-instruction conflict-free, 22 for
-// random nodes, 60 when 6 lanes hit one address - the natural order of the 6 tets around a cube diagonal).
-// Greedy first-fit: every aligned run of 32 element slots (= one half-wave of one sweep) keeps, per
-// vertex slot, a 32-bit mask of the banks already taken by OWNED nodes; an element goes to the first
-// half where all its owned vertices find their bank free, else to the half with the fewest clashes.
-void reorder_for_atomics(std::vector<uint16_t> &conn, int64_t off, int32_t n_elem, int32_t n_owned,
-                         std::vector<uint16_t> &scratch) {
+// Re-order (and re-orient) the element copies of one block for the LDS traffic of the element phase.
+// Every per-node quantity lives in LDS bank pair (slot mod 32) (saa_plan.h, LDS image), and an LDS
+// wave-instruction (ds_read_b64 of one plane, ds_add_f64 of one force component) is executed per
+// vertex slot over two 32-lane halves; lanes of a half that share a bank pair are serialised, lanes
+// adding to the SAME address even more so (gfx950, tools/lds_microbench.hip: ds_add_f64 costs 7
+// cycles conflict-free, 22 for random nodes, 60 when 6 lanes hit one address - the natural order of
+// the 6 tets around a cube diagonal).
+// Packing, one half-wave (32 element slots) at a time: scan the not yet placed elements and take
+// those for which one of the 12 EVEN vertex permutations (orientation, hence signed detJ, is
+// preserved; the nodal forces follow their vertices) puts all four vertices on bank pairs still
+// free in that half.  If the scan window runs dry the cheapest clash is taken (a clash on an owned
+// vertex costs a read and an atomic, on a halo vertex only a read).
+// Returns through mult_sum / mult_cnt the worst bank multiplicity summed over (half, slot).
+constexpr int kEvenPerms[12][4] = {{0, 1, 2, 3}, {0, 2, 3, 1}, {0, 3, 1, 2}, {1, 0, 3, 2}, {1, 2, 0, 3}, {1, 3, 2, 0},
+                                   {2, 0, 1, 3}, {2, 1, 3, 0}, {2, 3, 0, 1}, {3, 0, 2, 1}, {3, 1, 0, 2}, {3, 2, 1, 0}};
+
+void reorder_for_lds(std::vector<uint16_t> &conn, int64_t off, int32_t n_elem, int32_t owned_limit,
+                     std::vector<uint16_t> &scratch, double &mult_sum, int64_t &mult_cnt) {
   constexpr int kHalf = 32;
-  if (n_elem <= 1) return;
+  constexpr int kWindow = 768;  // pool elements examined per half before clashes are accepted
+  if (n_elem <= 0) return;
   const int32_t n_halves = (n_elem + kHalf - 1) / kHalf;
-  const int32_t last_cap = n_elem - (n_halves - 1) * kHalf;
-  std::vector<int32_t> fill(n_halves, 0);
-  std::vector<uint32_t> taken(static_cast<size_t>(n_halves) * 4, 0);
-  std::vector<int32_t> place(n_elem);
-  auto cap = [&](int32_t h) { return h == n_halves - 1 ? last_cap : kHalf; };
-  auto clashes = [&](int32_t h, const uint16_t *c) {
-    int k = 0;
-    for (int a = 0; a < 4; ++a)
-      if (c[a] < n_owned && (taken[static_cast<size_t>(h) * 4 + a] >> (c[a] & 31) & 1u)) ++k;
-    return k;
-  };
-  int32_t first_open = 0, cursor = 0;
-  for (int32_t e = 0; e < n_elem; ++e) {
-    const uint16_t *c = &conn[4 * static_cast<size_t>(off + e)];
-    while (first_open < n_halves && fill[first_open] >= cap(first_open)) ++first_open;
-    const int32_t span = n_halves - first_open;
-    int32_t best = -1, best_k = 5;
-    // rotating start: neighbouring elements (which share nodes) land in different halves
-    for (int32_t t = 0; t < span; ++t) {
-      const int32_t h = first_open + (cursor + t) % span;
-      if (fill[h] >= cap(h)) continue;
-      const int k = clashes(h, c);
-      if (k < best_k) {
-        best_k = k;
-        best = h;
-        if (k == 0) break;
+  std::vector<int32_t> pool(n_elem);
+  for (int32_t e = 0; e < n_elem; ++e) pool[e] = e;
+  scratch.resize(4 * static_cast<size_t>(n_elem));
+  const uint16_t *src = &conn[4 * static_cast<size_t>(off)];
+  int32_t out = 0;
+  for (int32_t h = 0; h < n_halves; ++h) {
+    const int32_t cap = std::min<int32_t>(kHalf, n_elem - out);
+    uint32_t taken[4] = {0, 0, 0, 0};
+    int32_t placed = 0;
+    auto put = [&](int32_t pool_pos, int perm) {
+      const uint16_t *c = src + 4 * static_cast<size_t>(pool[pool_pos]);
+      for (int a = 0; a < 4; ++a) {
+        const uint16_t v = c[kEvenPerms[perm][a]];
+        scratch[4 * static_cast<size_t>(out) + a] = v;
+        taken[a] |= 1u << (v & 31);
+      }
+      ++out;
+      ++placed;
+      pool[pool_pos] = -1;
+    };
+    // pass 1: clash-free placements
+    const int32_t lim = std::min<int32_t>(static_cast<int32_t>(pool.size()), kWindow);
+    for (int32_t p = 0; p < lim && placed < cap; ++p) {
+      const uint16_t *c = src + 4 * static_cast<size_t>(pool[p]);
+      const uint32_t r[4] = {c[0] & 31u, c[1] & 31u, c[2] & 31u, c[3] & 31u};
+      for (int q = 0; q < 12; ++q) {
+        const int *pm = kEvenPerms[q];
+        if (((taken[0] >> r[pm[0]]) | (taken[1] >> r[pm[1]]) | (taken[2] >> r[pm[2]]) | (taken[3] >> r[pm[3]])) & 1u)
+          continue;
+        put(p, q);
+        break;
       }
     }
-    ++cursor;
-    place[e] = best * kHalf + fill[best]++;
-    for (int a = 0; a < 4; ++a)
-      if (c[a] < n_owned) taken[static_cast<size_t>(best) * 4 + a] |= 1u << (c[a] & 31);
+    // pass 2: fill the rest of the half where it hurts least.  An LDS instruction costs its WORST bank
+    // multiplicity, so once a slot has one doubled bank further doublings on other banks of that slot are
+    // free.  Reads (6 x ds_read_b64, ~2 cycles per level) see every vertex, atomics (3 x ds_add_f64, ~7
+    // cycles per level) only owned ones.
+    if (placed < cap) {
+      uint8_t cnt_all[4][32] = {}, cnt_own[4][32] = {};
+      int max_all[4] = {0, 0, 0, 0}, max_own[4] = {0, 0, 0, 0};
+      for (int32_t l = 0; l < placed; ++l)
+        for (int a = 0; a < 4; ++a) {
+          const uint16_t v = scratch[4 * static_cast<size_t>(out - placed + l) + a];
+          max_all[a] = std::max<int>(max_all[a], ++cnt_all[a][v & 31]);
+          if (v < owned_limit) max_own[a] = std::max<int>(max_own[a], ++cnt_own[a][v & 31]);
+        }
+      while (placed < cap) {
+        int32_t best_p = -1, best_q = 0, best_k = 1 << 30;
+        for (int32_t p = 0; p < lim && best_k > 0; ++p) {
+          if (pool[p] < 0) continue;
+          const uint16_t *c = src + 4 * static_cast<size_t>(pool[p]);
+          for (int q = 0; q < 12; ++q) {
+            int k = 0;
+            for (int a = 0; a < 4; ++a) {
+              const uint16_t v = c[kEvenPerms[q][a]];
+              if (cnt_all[a][v & 31] + 1 > max_all[a]) k += 12;
+              if (v < owned_limit && cnt_own[a][v & 31] + 1 > max_own[a]) k += 21;
+            }
+            if (k < best_k) {
+              best_k = k;
+              best_p = p;
+              best_q = q;
+              if (k == 0) break;
+            }
+          }
+        }
+        const uint16_t *c = src + 4 * static_cast<size_t>(pool[best_p]);
+        for (int a = 0; a < 4; ++a) {
+          const uint16_t v = c[kEvenPerms[best_q][a]];
+          max_all[a] = std::max<int>(max_all[a], ++cnt_all[a][v & 31]);
+          if (v < owned_limit) max_own[a] = std::max<int>(max_own[a], ++cnt_own[a][v & 31]);
+        }
+        put(best_p, best_q);
+      }
+    }
+    pool.erase(std::remove(pool.begin(), pool.begin() + lim, -1), pool.begin() + lim);
+    // quality of this half
+    for (int a = 0; a < 4; ++a) {
+      int cnt[32] = {0};
+      int worst = 0;
+      for (int32_t l = 0; l < cap; ++l)
+        worst = std::max(worst, ++cnt[scratch[4 * static_cast<size_t>(out - cap + l) + a] & 31]);
+      mult_sum += worst;
+      ++mult_cnt;
+    }
   }
-  scratch.resize(4 * static_cast<size_t>(n_elem));
-  for (int32_t e = 0; e < n_elem; ++e)
-    for (int a = 0; a < 4; ++a)
-      scratch[4 * static_cast<size_t>(place[e]) + a] = conn[4 * static_cast<size_t>(off + e) + a];
   std::copy(scratch.begin(), scratch.end(), conn.begin() + 4 * off);
 }
 
@@ -171,6 +230,8 @@ bool build_once(int32_t n_nodes, int32_t n_elems, const double *xyz, const int32
   std::vector<int32_t> tmp;
   std::vector<uint16_t> reorder_scratch;
   std::vector<char> interior_flag;
+  double mult_sum = 0.0;
+  int64_t mult_cnt = 0;
   for (int32_t b = 0; b < n_blocks; ++b) {
     BlockDesc &d = plan.blocks[b];
     d.node_start = block_start[b];
@@ -224,14 +285,19 @@ bool build_once(int32_t n_nodes, int32_t n_elems, const double *xyz, const int32
       (void)hi_i;
       interior_flag.clear();
     }
-    d.pad_ = 0;
-    reorder_for_atomics(plan.conn, off[b], d.n_interior, d.n_owned, reorder_scratch);
-    reorder_for_atomics(plan.conn, off[b] + d.n_interior, d.n_elem - d.n_interior, d.n_owned, reorder_scratch);
+    d.owned_limit = lds_index(d.n_owned);
+    // connectivity becomes LDS slots (tile/plane layout of saa_plan.h); slot mod 32 = bank pair
+    for (int64_t c = 4 * off[b]; c < 4 * off[b + 1]; ++c)
+      plan.conn[c] = static_cast<uint16_t>(lds_index(plan.conn[c]));
+    reorder_for_lds(plan.conn, off[b], d.n_interior, d.owned_limit, reorder_scratch, mult_sum, mult_cnt);
+    reorder_for_lds(plan.conn, off[b] + d.n_interior, d.n_elem - d.n_interior, d.owned_limit, reorder_scratch,
+                    mult_sum, mult_cnt);
     plan.halo_ids.insert(plan.halo_ids.end(), tmp.begin(), tmp.end());
     plan.max_owned = std::max(plan.max_owned, d.n_owned);
     plan.max_local = std::max(plan.max_local, d.n_owned + d.n_halo);
     plan.n_halo_total += d.n_halo;
   }
+  plan.lds_conflict_factor = mult_cnt ? mult_sum / mult_cnt : 1.0;
   return true;
 }
 

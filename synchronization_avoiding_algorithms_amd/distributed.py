@@ -1,0 +1,146 @@
+"""One mesh partition per GPU: the synchronised / sync-avoiding stepping of the reference drivers.
+
+Reference behaviour being replaced (all in /root/reference):
+
+* ``syn_cpus`` (``Tools/Distributed_tools.py:77-92``): every step each rank pickles its whole local
+  force vector *and* its node list to rank 0, which scatter-adds into a global ``(3N,1)`` vector and
+  broadcasts it back.  Here only the forces of *shared* nodes travel: they are written by the fused
+  step kernel into a compact interface buffer indexed by the sorted ``Global_shared`` list
+  (``Data_prepare.py:121-124``), summed with ONE ``all_reduce`` (RCCL over xGMI when the process
+  group is ``nccl``) and applied to the shared nodes by a small finish kernel.  Interior nodes never
+  wait for the collective: their update is already done when it starts.
+* the hybrid loop of ``Online_predictor.py:251-318``: ``n_past*filter_size`` synchronised steps, then
+  windows of ``n_future*filter_size`` steps without any communication in which the shared dofs are
+  overwritten by LSTM predictions (``:298``) and recorded as the next window's history (``:301``).
+
+The per-partition solver is injected (``solver_factory``) so that the orchestration in this file is
+exercised on CPU with ``gloo`` by the tests; the product factory is :class:`HipExplicitSolver`.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional
+
+import numpy as np
+
+from . import fem_setup as fs
+from .mesh import clamp_nodes
+
+
+def _hip_factory(**kw):
+    from .solver import HipExplicitSolver
+
+    return HipExplicitSolver(**kw)
+
+
+class PartitionedSolver:
+    """This rank's partition of a replicated mesh (``Data_prepare.py:76-79``) plus its exchange."""
+
+    def __init__(self, points, cells, facets_or_dirichlet_nodes, epart, rank, world,
+                 E=1e6, nu=0.3, rho=1.0, fz=0.5, alpha=0.5, gamma=0.9, device=0, process_group=None,
+                 tensor_device=None, solver_factory: Optional[Callable] = None, block_nodes=0, threads=0):
+        import torch
+
+        self.rank, self.world = int(rank), int(world)
+        self.group = process_group
+        points = np.ascontiguousarray(points, dtype=np.float64)
+        cells = np.asarray(cells, dtype=np.int64)
+        dn = np.asarray(facets_or_dirichlet_nodes)
+        if dn.ndim == 2:  # triangle facets: detect the clamp like Data_prepare.py:127-136
+            from .mesh import Mesh
+
+            dn = clamp_nodes(Mesh(points, {"tetra": cells, "triangle": dn}))
+        self.lmd, self.mu = fs.lame(E, nu)
+        self.layouts, self.global_shared = fs.build_layouts(cells, epart, world, len(points), dn)
+        self.layout = lay = self.layouts[rank]
+        lumped, fpre = fs.lumped_mass_and_load(points, cells, rho, fz)
+        # min over ranks of the local CFL steps == CFL step of the whole mesh (Data_prepare.py:147-154)
+        self.dt = fs.cfl_dt(points, cells, E, nu, rho, gamma)
+        self.alpha = alpha
+        factory = solver_factory or _hip_factory
+        self.solver = factory(points=points[lay.nodes], cells=lay.cells_local, l_M=lumped[lay.local_dof],
+                              F_rankwise=fpre[lay.local_dof], dirichlet_dofs=lay.dirichlet_dofs,
+                              lmd=self.lmd, mu=self.mu, dt=self.dt, alpha=alpha,
+                              shared_local=lay.shared_local, shared_slots=lay.shared_slots,
+                              n_global_shared=len(self.global_shared), device=device,
+                              block_nodes=block_nodes, threads=threads)
+        self.tensor_device = tensor_device if tensor_device is not None else torch.device("cuda", device)
+        self.iface = torch.zeros(3 * len(self.global_shared), dtype=torch.float64, device=self.tensor_device)
+        if self.world > 1:
+            self.solver.set_interface_buffer(self.iface)
+        if self.tensor_device.type == "cuda":
+            self.solver.set_stream(torch.cuda.current_stream(self.tensor_device).cuda_stream)
+        self.input_size = 3 * len(lay.shared_nodes)          # Online_predictor.py:126
+        self.steps_done = 0
+
+    # -- the three kinds of step ---------------------------------------------------------------------
+    def step_synced(self, nsteps=1, hist=None, hist_row0=0):
+        """``MODEL=False`` steps (``Dynamic_solver.py:22-32``): local update, all-reduce of the shared
+        forces, shared-node update; optional history record (``Online_predictor.py:260``)."""
+        import torch.distributed as dist
+
+        if self.world == 1:
+            if hist is None or self.input_size == 0:
+                self.solver.step(nsteps)
+            else:  # serial run with a history request: nothing is shared, nothing to record
+                self.solver.step(nsteps)
+            self.steps_done += nsteps
+            return
+        for k in range(nsteps):
+            self.solver.step_begin()
+            dist.all_reduce(self.iface, group=self.group)
+            self.solver.step_finish(hist, hist_row0 + k)
+        self.steps_done += nsteps
+
+    def step_local(self, nsteps=1):
+        """``MODEL=True`` steps without overwrite: every rank advances on its own partial forces."""
+        self.solver.step(nsteps)
+        self.steps_done += nsteps
+
+    def step_predicted(self, nsteps, table, table_row0=0, hist=None, hist_row0=0):
+        """Sync-free steps with the halo overwrite of ``Online_predictor.py:287-316``."""
+        self.solver.step_predicted(nsteps, table, table_row0, hist, hist_row0)
+        self.steps_done += nsteps
+
+    # -- convenience ---------------------------------------------------------------------------------
+    def get_state(self):
+        return self.solver.get_state()
+
+    def close(self):
+        self.solver.close()
+
+
+def run_hybrid(part: PartitionedSolver, n_steps, predictor, n_past, n_future, filter_size, save=None):
+    """``Online_predictor.py:251-318`` on one rank.
+
+    ``predictor(n, hist) -> table``: ``hist`` is the ``(n_steps, input_size)`` float64 history tensor on the
+    solver's device (``d_sol_shared``), the result a ``(n_future*filter_size, input_size)`` float64 tensor
+    (``encoder_decoder_predictor``).  ``save(i, part)`` is called after every step that the reference would
+    store (``save_every`` logic lives in the callback).  Returns the history tensor.
+    """
+    import torch
+
+    hist = torch.zeros((n_steps, max(part.input_size, 1)), dtype=torch.float64, device=part.tensor_device)
+    hist = hist[:, :part.input_size] if part.input_size else hist[:, :0]
+    hist = hist.contiguous()
+    i_cri = n_past * filter_size - 1
+    window = n_future * filter_size
+    i = 0
+    while i < n_steps:
+        if i <= i_cri:
+            n = min(i_cri + 1, n_steps) - i if save is None else 1
+            part.step_synced(n, hist if part.input_size else None, i)
+            i += n
+            if save is not None:
+                save(i - 1, part)
+        else:
+            table = predictor(i, hist)
+            todo = min(window, n_steps - i)
+            if save is None:
+                part.step_predicted(todo, table, 0, hist if part.input_size else None, i)
+                i += todo
+            else:
+                for k in range(todo):
+                    part.step_predicted(1, table, k, hist if part.input_size else None, i)
+                    i += 1
+                    save(i - 1, part)
+    return hist

@@ -1,0 +1,73 @@
+"""N > 1 orchestration on CPU: two gloo ranks drive ``PartitionedSolver`` (product code) over a CPU
+double of the per-partition solver; the result must equal the reference's own 2-rank run."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import GOLDEN, REPO, load_golden, rel_l2
+
+
+def _worker(rank, world, port, steps, out_dir):
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from cpu_double import CpuSolverDouble
+    from synchronization_avoiding_algorithms_amd.distributed import PartitionedSolver
+
+    g = np.load(os.path.join(GOLDEN, "beam_coarse_mesh.npz"))
+    t = np.load(os.path.join(GOLDEN, "tworank_trajectory.npz"))
+    part = PartitionedSolver(g["points"], g["tetra"], g["triangle"], t["epart"], rank, world,
+                             tensor_device=torch.device("cpu"),
+                             solver_factory=lambda **kw: CpuSolverDouble(**kw))
+    assert part.dt == float(t["dt"])
+    assert np.array_equal(part.layout.nodes, t[f"r{rank}_local_nodes"])
+    assert np.array_equal(part.layout.shared_nodes, t[f"r{rank}_shared_nodes"])
+    assert np.array_equal(part.global_shared, t["Global_shared"])
+    assert np.array_equal(part.layout.dirichlet_dofs, t[f"r{rank}_local_dirichlet"])
+    snaps, done = {}, 0
+    for s in steps:
+        part.step_synced(s - done)
+        done = s
+        snaps[s] = part.get_state()[0][:, 0]
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), **{str(k): v for k, v in snaps.items()})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sync_matches_reference(tmp_path):
+    steps = (1, 10, 100, 1000)
+    port = 29500 + os.getpid() % 2000
+    mp.spawn(_worker, args=(2, port, steps, str(tmp_path)), nprocs=2, join=True)
+    t = load_golden("tworank_trajectory.npz")
+    bound = {1: 1e-15, 10: 1e-14, 100: 1e-13, 1000: 5e-12}
+    for r in range(2):
+        got = np.load(tmp_path / f"rank{r}.npz")
+        for s in steps:
+            err = rel_l2(got[str(s)], t[f"r{r}_step_{s}"])
+            assert err < bound[s], (r, s, err)
+
+
+def test_layouts_follow_reference_orderings(beam_coarse):
+    """shared-node order = other ranks' first-touch order (Distributed_tools.py:29-40), 3 ranks."""
+    from oracle import fem_oracle as fo
+    from synchronization_avoiding_algorithms_amd import fem_setup as fs
+    from synchronization_avoiding_algorithms_amd.mesh import clamp_nodes, slab_partition
+
+    epart = slab_partition(beam_coarse, 3)
+    layouts, gshared = fs.build_layouts(beam_coarse.tets, epart, 3, len(beam_coarse.points),
+                                        clamp_nodes(beam_coarse))
+    lists = [fo.rankwise_dist(r, epart, beam_coarse.tets)[1] for r in range(3)]
+    shared = [fo.find_shared_nodes(r, lists) for r in range(3)]
+    assert np.array_equal(gshared, fo.sort_shared(shared))
+    for r in range(3):
+        assert np.array_equal(layouts[r].nodes, lists[r])
+        assert np.array_equal(layouts[r].shared_nodes, shared[r])
+        assert np.array_equal(gshared[layouts[r].shared_slots], shared[r])
+        assert np.array_equal(layouts[r].loc_dof_shared,
+                              fo.node_to_dof(fo.local_index(shared[r], lists[r])))

@@ -1,0 +1,60 @@
+"""Two ranks sharing the one GPU of the test box: the real HIP begin / all-reduce / finish path
+(gloo moves the CUDA interface buffer; the driver's multi-GPU bench uses nccl = RCCL) against the
+reference's own 2-rank trajectory, and the predicted-phase overwrite / history kernels."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import GOLDEN, REPO, load_golden, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, world, port, steps, out_dir):
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from synchronization_avoiding_algorithms_amd.distributed import PartitionedSolver
+
+    g = np.load(os.path.join(GOLDEN, "beam_coarse_mesh.npz"))
+    t = np.load(os.path.join(GOLDEN, "tworank_trajectory.npz"))
+    part = PartitionedSolver(g["points"], g["tetra"], g["triangle"], t["epart"], rank, world, device=0)
+    hist = torch.zeros((max(steps), part.input_size), dtype=torch.float64, device="cuda")
+    snaps, done = {}, 0
+    for s in steps:
+        part.step_synced(s - done, hist, done)
+        done = s
+        snaps[s] = part.get_state()[0][:, 0]
+    torch.cuda.synchronize()
+    h = hist.cpu().numpy()
+    # the recorded history is the shared dofs of every step (Online_predictor.py:260)
+    assert np.array_equal(h[done - 1], snaps[done][part.layout.loc_dof_shared])
+    # predicted phase: overwrite with a table row and record it (Online_predictor.py:298-301)
+    table = torch.arange(3 * part.input_size, dtype=torch.float64, device="cuda").reshape(3, -1) * 1e-6
+    hist2 = torch.zeros((3, part.input_size), dtype=torch.float64, device="cuda")
+    part.step_predicted(3, table, 0, hist2, 0)
+    d0 = part.get_state()[0][:, 0]
+    assert np.array_equal(d0[part.layout.loc_dof_shared], table[2].cpu().numpy())
+    assert torch.equal(hist2, table)
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), **{str(k): v for k, v in snaps.items()})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_match_reference(tmp_path):
+    steps = (1, 10, 100, 1000, 5000)
+    port = 29500 + os.getpid() % 2000
+    mp.spawn(_worker, args=(2, port, steps, str(tmp_path)), nprocs=2, join=True)
+    t = load_golden("tworank_trajectory.npz")
+    bound = {1: 1e-15, 10: 1e-14, 100: 1e-13, 1000: 5e-12, 5000: 5e-11}
+    for r in range(2):
+        got = np.load(tmp_path / f"rank{r}.npz")
+        for s in steps:
+            err = rel_l2(got[str(s)], t[f"r{r}_step_{s}"])
+            assert err < bound[s], (r, s, err)
