@@ -78,11 +78,8 @@ class PartitionedSolver:
         forces, shared-node update; optional history record (``Online_predictor.py:260``)."""
         import torch.distributed as dist
 
-        if self.world == 1:
-            if hist is None or self.input_size == 0:
-                self.solver.step(nsteps)
-            else:  # serial run with a history request: nothing is shared, nothing to record
-                self.solver.step(nsteps)
+        if self.world == 1:  # serial: nothing is shared, nothing to exchange or record
+            self.solver.step(nsteps)
             self.steps_done += nsteps
             return
         for k in range(nsteps):

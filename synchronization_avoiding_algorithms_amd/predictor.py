@@ -1,0 +1,162 @@
+"""LSTM encoder-decoder shared-node predictor on PyTorch-ROCm.
+
+Same architecture, parameter names and numerics as the reference's per-rank model
+(/root/reference ``Tools/DNN_tools.py:16-98``: 2-layer bidirectional LSTM encoder whose last layer's
+forward|backward ``(h, c)`` seed a 1-layer LSTM decoder of width ``2H`` followed by ``Linear(2H -> in)``)
+so that a ``model.pth`` written by the reference's ``Model_training.py:179-180`` loads unchanged.
+
+What differs is the execution: the reference runs ``filter_size`` (=150) sequential batch-1 passes on
+the CPU per prediction window (``Tools/DNN_prediction.py:38-55``); here the phase offsets form ONE batch
+on the GPU, the shared-dof history never leaves the device, and the decoder's ``n_future`` steps reuse
+pre-allocated buffers.  Arithmetic stays fp32 like the reference (``.float()`` at ``DNN_prediction.py:49``).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+
+class LSTM_Encoder(nn.Module):
+    """``DNN_tools.py:16-59``; returns the last layer's states as ``(1, N, D*H)``."""
+
+    def __init__(self, input_size, hidden_size, num_layers=2, Bi_dir=True, dp=0.0):
+        super().__init__()
+        self.input_size, self.hidden_size, self.num_layers = input_size, hidden_size, num_layers
+        self.D = 2 if Bi_dir else 1
+        self.lstm_encoder = nn.LSTM(input_size=input_size, hidden_size=hidden_size, num_layers=num_layers,
+                                    batch_first=True, dropout=dp, bidirectional=bool(Bi_dir))
+
+    def forward(self, x):
+        _, (hn, cn) = self.lstm_encoder(x)
+        n = x.shape[0]
+        hn = hn.view(self.num_layers, self.D, n, self.hidden_size)[-1]
+        cn = cn.view(self.num_layers, self.D, n, self.hidden_size)[-1]
+        if self.D == 2:
+            return torch.cat((hn[0], hn[1]), 1).unsqueeze(0), torch.cat((cn[0], cn[1]), 1).unsqueeze(0)
+        return hn, cn
+
+
+class LSTM_Decoder(nn.Module):
+    """``DNN_tools.py:63-80``: one recursive step per call."""
+
+    def __init__(self, input_size, hidden_size, Bi_dir=True, dp=0.0):
+        super().__init__()
+        self.input_size = input_size
+        self.hidden_size = hidden_size * 2 if Bi_dir else hidden_size
+        self.lstm_decoder = nn.LSTM(input_size=input_size, hidden_size=self.hidden_size, num_layers=1,
+                                    batch_first=True, bidirectional=False)
+        self.fc = nn.Linear(self.hidden_size, input_size)
+        self.dropout = nn.Dropout(dp)
+
+    def forward(self, x, encoded_hn, encoded_cn):
+        out, (hn, cn) = self.lstm_decoder(x.unsqueeze(1), (encoded_hn, encoded_cn))
+        return self.fc(self.dropout(out.squeeze(1))), hn, cn
+
+
+class LSTM_encoder_decoder(nn.Module):
+    """``DNN_tools.py:85-98``; state_dict keys ``encoder.lstm_encoder.*``, ``decoder.lstm_decoder.*``,
+    ``decoder.fc.*``."""
+
+    def __init__(self, input_size, hidden_size, num_layers_encoder=2, Bi_dir_encoder=True, dp_encoder=0.0,
+                 dp_decoder=0.0):
+        super().__init__()
+        self.input_size, self.hidden_size = input_size, hidden_size
+        self.encoder = LSTM_Encoder(input_size, hidden_size, num_layers_encoder, Bi_dir_encoder, dp_encoder)
+        self.decoder = LSTM_Decoder(input_size, hidden_size, Bi_dir_encoder, dp_decoder)
+
+
+def call_model(device, filter_size, input_size, hidden_size, model_path):
+    """``DNN_prediction.py:18-34``: 2 encoder layers, bidirectional, no dropout; weights from a local
+    ``state_dict`` file (loaded with ``weights_only=True`` - nothing in the file is executed)."""
+    model = LSTM_encoder_decoder(input_size, hidden_size, 2, True, 0.0, 0.0)
+    model.load_state_dict(torch.load(model_path, map_location=device, weights_only=True))
+    return model.to(device)
+
+
+def scale_forward(X, scale_max, scale_min):
+    """``DNN_tools.py:272-275``: maps the training range to [-1, 0]."""
+    return (X - scale_max) / (-scale_min + scale_max)
+
+
+def scale_it_back(X, scale_max, scale_min):
+    """``DNN_tools.py:277-279``."""
+    return X * (scale_max - scale_min) + scale_max
+
+
+def model_predict(device, model, X, n_future):
+    """``DNN_tools.py:212-234`` for one window ``X (n_past, in)`` or a batch ``(B, n_past, in)``."""
+    model.eval()
+    single = X.dim() == 2
+    if single:
+        X = X.unsqueeze(0)
+    with torch.no_grad():
+        h, c = model.encoder(X)
+        out = torch.empty((X.shape[0], n_future, X.shape[2]), device=X.device, dtype=X.dtype)
+        inp = X[:, -1, :]
+        for i in range(n_future):
+            inp, h, c = model.decoder(inp, h, c)
+            out[:, i, :] = inp
+    return out[0] if single else out
+
+
+def _phase_indices(n, n_p, n_f, n_s):
+    """History / future row indices of every phase offset (``DNN_prediction.py:44-45``)."""
+    past = [np.arange(i + n - n_p * n_s, i + n - 1, n_s) for i in range(n_s)]
+    fut = [np.arange(i + n, n + i + n_f * n_s - 1, n_s) - n for i in range(n_s)]
+    return past, fut
+
+
+def predict_table(model, n, n_p, n_f, n_s, hist, scale_max, scale_min):
+    """Batched ``encoder_decoder_predictor`` on whatever device ``hist`` (float64, ``(steps, in)``) lives on.
+
+    Returns the float64 ``(n_s*n_f, in)`` table whose row ``k`` is the prediction for step ``n + k``.
+    """
+    past, fut = _phase_indices(n, n_p, n_f, n_s)
+    if len({len(p) for p in past}) != 1 or len({len(f) for f in fut}) != 1:
+        raise ValueError("phase windows of unequal length (n_s == 1?) cannot be batched")
+    dev = hist.device
+    pidx = torch.as_tensor(np.stack(past), device=dev)                      # (n_s, n_p)
+    X = scale_forward(hist[pidx], scale_max, scale_min).float()            # fp64 scaling, then .float() (:48-49)
+    Y = model_predict(dev, model, X, len(fut[0]))                          # (n_s, n_f, in) fp32
+    Y = scale_it_back(Y, scale_max, scale_min)                             # fp32 like the reference (:51)
+    table = torch.zeros((n_s * n_f, hist.shape[1]), dtype=torch.float64, device=dev)
+    fidx = torch.as_tensor(np.stack(fut), device=dev)                      # (n_s, n_f)
+    table[fidx.reshape(-1)] = Y.reshape(-1, hist.shape[1]).double()
+    return table
+
+
+def encoder_decoder_predictor(device, n, model, n_p, n_f, n_s, input_size, d_sol, scale_max, scale_min):
+    """Drop-in for ``DNN_prediction.py:38-55``: NumPy history in, float64 NumPy table out."""
+    lo = n - n_p * n_s
+    hist = torch.zeros((n, input_size), dtype=torch.float64, device=device)
+    hist[lo:n] = torch.from_numpy(np.ascontiguousarray(d_sol[lo:n, :])).to(device)
+    return predict_table(model, n, n_p, n_f, n_s, hist, scale_max, scale_min).cpu().numpy()
+
+
+def scaling_constants(displacement_shared, filter_size, n_past, n_future, cut_off):
+    """``scale_max, scale_min`` of ``Online_predictor.py:130-136``.
+
+    ``displacement_shared`` is the ``(input_size, n_steps)`` array ``Shared_extraction.py:36-39`` stores.
+    The reference windows the first ``cut_off`` share of the ``filter_size``-subsampled series
+    (``DNN_tools.py:284-313``) and takes max/min over all windows in fp32 (``:259-269``); the windows
+    jointly cover every retained sample, hence max/min of the fp32 series.
+    """
+    data = np.asarray(displacement_shared).transpose()
+    data = data[0:int(cut_off * len(data)), :][0::filter_size, :]
+    if data.shape[0] < n_past + n_future:
+        raise ValueError("trajectory too short for one (n_past, n_future) window")
+    data32 = torch.from_numpy(np.ascontiguousarray(data)).float()
+    return data32.max().item(), data32.min().item()
+
+
+class DevicePredictor:
+    """Callable for :func:`distributed.run_hybrid`: keeps model and scaling on the solver's device."""
+
+    def __init__(self, model, n_past, n_future, filter_size, scale_max, scale_min):
+        self.model = model.eval()
+        self.n_p, self.n_f, self.n_s = n_past, n_future, filter_size
+        self.scale_max, self.scale_min = float(scale_max), float(scale_min)
+
+    def __call__(self, n, hist):
+        return predict_table(self.model, n, self.n_p, self.n_f, self.n_s, hist, self.scale_max, self.scale_min)

@@ -1,0 +1,79 @@
+"""The C-ABI library loads on a GPU-less host and exports every function include/saa_hip.h declares
+(no compute call is made here); host-only plan builder sanity."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import REPO
+from synchronization_avoiding_algorithms_amd import _lib
+
+
+def _declared_functions():
+    text = open(os.path.join(REPO, "include", "saa_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(saa_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_header_and_binding_agree():
+    names = _declared_functions()
+    assert len(names) >= 20
+    assert sorted(_lib.SIGNATURES) == names
+
+
+def test_library_exports_every_declared_symbol():
+    _lib.build_library()
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in _declared_functions():
+        assert hasattr(lib, name), name
+    assert _lib.load().saa_abi_version() == 1
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _lib.load()
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.join(REPO, "synchronization_avoiding_algorithms_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                src = open(os.path.join(root, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+
+
+def test_host_plan_properties(beam_coarse):
+    from synchronization_avoiding_algorithms_amd import plan_host_stats
+    from synchronization_avoiding_algorithms_amd.mesh import structured_beam
+
+    st = plan_host_stats(beam_coarse.points, beam_coarse.tets)
+    assert st["n_blocks"] == 1 and st["n_elem_copies"] == 256 and st["n_halo_total"] == 0
+    mesh = structured_beam(6)
+    for bn in (64, 200, 0):
+        st = plan_host_stats(mesh.points, mesh.tets, bn)
+        assert st["n_elem_copies"] >= len(mesh.tets)
+        assert st["max_local"] >= st["max_owned"] and st["lds_bytes"] <= 160 * 1024
+        assert 1.0 <= st["lds_conflict_factor"] < 4.0
+    # malformed input is rejected with a message, not a crash
+    bad = mesh.tets.copy()
+    bad[0, 0] = len(mesh.points) + 5
+    with pytest.raises(_lib.SaaError, match="outside"):
+        plan_host_stats(mesh.points, bad)
+
+
+def test_synthetic_beam_shapes():
+    from synchronization_avoiding_algorithms_amd import fem_setup as fs
+    from synchronization_avoiding_algorithms_amd.mesh import clamp_nodes, structured_beam
+
+    m = structured_beam(2)
+    assert len(m.tets) == 25 * 2 * 2 * 2 * 6 and len(m.points) == 51 * 3 * 3
+    vol = fs.signed_volumes(m.points, m.tets)
+    assert (vol > 0).all() and np.isclose(vol.sum(), 25.0)
+    assert len(clamp_nodes(m)) == 9
+    lumped, load = fs.lumped_mass_and_load(m.points, m.tets, 1.0, 0.5)
+    assert np.isclose(lumped.sum() / 3, 25.0) and np.allclose(load.reshape(-1, 3).sum(0), [0, -12.5, -12.5])

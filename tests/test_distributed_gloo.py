@@ -71,3 +71,49 @@ def test_layouts_follow_reference_orderings(beam_coarse):
         assert np.array_equal(gshared[layouts[r].shared_slots], shared[r])
         assert np.array_equal(layouts[r].loc_dof_shared,
                               fo.node_to_dof(fo.local_index(shared[r], lists[r])))
+
+
+def _hybrid_worker(rank, world, port, out_dir):
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from cpu_double import CpuSolverDouble
+    from synchronization_avoiding_algorithms_amd import predictor as pr
+    from synchronization_avoiding_algorithms_amd.distributed import PartitionedSolver, run_hybrid
+
+    g = np.load(os.path.join(GOLDEN, "beam_coarse_mesh.npz"))
+    h = np.load(os.path.join(GOLDEN, "hybrid_tworank.npz"))
+    T, n_p, n_f, n_s, hid = (int(h[k]) for k in ("test_num", "n_past", "n_future", "filter_size", "hidden_size"))
+    part = PartitionedSolver(g["points"], g["tetra"], g["triangle"], h["epart"], rank, world,
+                             tensor_device=torch.device("cpu"),
+                             solver_factory=lambda **kw: CpuSolverDouble(**kw))
+    assert np.array_equal(part.layout.loc_dof_shared, h[f"r{rank}_loc_dof_shared"])
+    model = pr.LSTM_encoder_decoder(part.input_size, hid)
+    model.load_state_dict({k[len(f"r{rank}_w::"):]: torch.from_numpy(h[k]) for k in h.files
+                           if k.startswith(f"r{rank}_w::")})
+    smax, smin = (float(v) for v in h[f"r{rank}_scale"])
+    saved = np.zeros((3 * len(part.layout.nodes), T))
+
+    def save(i, p):
+        saved[:, i] = p.get_state()[0][:, 0]
+
+    hist = run_hybrid(part, T, pr.DevicePredictor(model, n_p, n_f, n_s, smax, smin), n_p, n_f, n_s, save=save)
+    np.savez(os.path.join(out_dir, f"hyb{rank}.npz"), saved=saved, hist=hist.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_hybrid_loop_matches_reference(tmp_path):
+    """Online_predictor.py:251-318 re-enacted by distributed.run_hybrid + the batched predictor."""
+    port = 31500 + os.getpid() % 2000
+    mp.spawn(_hybrid_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    h = load_golden("hybrid_tworank.npz")
+    i_cri = int(h["n_past"]) * int(h["filter_size"]) - 1
+    for r in range(2):
+        got = np.load(tmp_path / f"hyb{r}.npz")
+        ref = h[f"r{r}_modeled"]
+        assert rel_l2(got["saved"][:, :i_cri + 1], ref[:, :i_cri + 1]) < 1e-13  # synchronised warm-up
+        assert rel_l2(got["saved"], ref) < 1e-5        # fp32 LSTM, batched vs batch-1
+        assert rel_l2(got["hist"], h[f"r{r}_d_sol_shared"]) < 1e-5

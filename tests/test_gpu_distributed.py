@@ -58,3 +58,58 @@ def test_two_ranks_on_one_gpu_match_reference(tmp_path):
         for s in steps:
             err = rel_l2(got[str(s)], t[f"r{r}_step_{s}"])
             assert err < bound[s], (r, s, err)
+
+
+def _workflow_worker(rank, world, port, out_dir):
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from synchronization_avoiding_algorithms_amd import drivers
+    from synchronization_avoiding_algorithms_amd.mesh import Mesh
+
+    g = np.load(os.path.join(GOLDEN, "beam_coarse_mesh.npz"))
+    h = np.load(os.path.join(GOLDEN, "hybrid_tworank.npz"))
+    mesh = Mesh(g["points"], {"tetra": g["tetra"], "triangle": g["triangle"]})
+    T, n_p, n_f, n_s, hid = (int(h[k]) for k in ("test_num", "n_past", "n_future", "filter_size", "hidden_size"))
+    _, truth = drivers.data_prepare(mesh, T, 1, out_dir, rank, world, epart=h["epart"])
+    dist.barrier()
+    _, shared = drivers.shared_extraction(out_dir, rank)
+    # the reference's weights at the path Online_predictor.py:139-140 builds
+    mpath = os.path.join(out_dir, drivers.PATHS["model"].format(r=rank, nB=10, nH=hid, lr=5e-4, ns=n_s))
+    os.makedirs(os.path.dirname(mpath), exist_ok=True)
+    torch.save({k[len(f"r{rank}_w::"):]: torch.from_numpy(h[k]) for k in h.files if k.startswith(f"r{rank}_w::")},
+               mpath)
+    _, modeled, hist = drivers.online_predictor(mesh, T, 1, out_dir, rank, world, epart=h["epart"], n_past=n_p,
+                                                n_future=n_f, filter_size=n_s, hidden_size=hid)
+    np.savez(os.path.join(out_dir, f"wf{rank}.npz"), truth=truth, shared=shared, modeled=modeled,
+             hist=hist.cpu().numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_reference_workflow_on_gpu(tmp_path):
+    """Data_prepare -> Shared_extraction -> Online_predictor (README.md:33-38) with the HIP solver and the
+    GPU-batched LSTM, against the same chain run by the reference itself (hybrid_tworank.npz)."""
+    port = 33500 + os.getpid() % 2000
+    mp.spawn(_workflow_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    h = load_golden("hybrid_tworank.npz")
+    i_cri = int(h["n_past"]) * int(h["filter_size"]) - 1
+    for r in range(2):
+        got = np.load(tmp_path / f"wf{r}.npz")
+        assert rel_l2(got["truth"][:, -1], h[f"r{r}_truth_last"]) < 1e-12
+        assert rel_l2(got["shared"], h[f"r{r}_shared_traj"]) < 1e-12
+        ref = h[f"r{r}_modeled"]
+        assert rel_l2(got["modeled"][:, :i_cri + 1], ref[:, :i_cri + 1]) < 1e-12
+        assert rel_l2(got["modeled"], ref) < 1e-4      # fp32 LSTM on MIOpen/rocBLAS vs CPU batch-1
+        assert rel_l2(got["hist"], h[f"r{r}_d_sol_shared"]) < 1e-4
+        # artefact names of the reference
+        for key in ("local_nodes", "shared", "elements", "truth", "modeled", "shared_traj"):
+            base = os.path.splitext(os.path.join(tmp_path, drivers_path(key, r)))[0]
+            assert any(os.path.exists(base + ext) for ext in (".csv", ".hdf5", ".npz")), base
+
+
+def drivers_path(key, r):
+    from synchronization_avoiding_algorithms_amd import drivers
+
+    return drivers.PATHS[key].format(r=r)

@@ -138,3 +138,27 @@ def test_error_paths(beam_coarse):
     d0, _, tn = sol.get_state()
     assert not d0[:3].any() and np.isfinite(d0).all() and tn > 0
     sol.close()
+
+
+def test_reference_style_driver_loop_with_dropin_tools(beam_coarse):
+    """The time loop of Data_prepare.py:223-240 written against the drop-in ``Tools`` names."""
+    from synchronization_avoiding_algorithms_amd.Tools.commons import Time_integration_displacement, elasticity
+    from synchronization_avoiding_algorithms_amd.Tools.Dynamic_solver import parallel_explicit_solver_dis_pre
+    from synchronization_avoiding_algorithms_amd.Tools.Mat_construction import Local_assembly_for_stiffness
+
+    g = load_golden("serial_setup.npz")
+    traj = load_golden("serial_trajectory.npz")
+    E, nu = 1e6, 0.3
+    elas = elasticity(E * nu / ((1 + nu) * (1 - 2 * nu)), E / (2 * (1 + nu)), 1, 0.5, True)
+    Points, nodes = beam_coarse.points, g["local_nodes"]
+    LocalK = Local_assembly_for_stiffness(nodes, beam_coarse.tets[g["local_elements"]], Points, 1, 4, elas, 0)
+    assert rel_l2(LocalK.dot(g["d_rand"]), g["Kd_rand"]) < 1e-13
+    d_0, d_n, tn, dt = g["d0"], g["dn"], 0, g["dt"]
+    for i in range(100):
+        Time = Time_integration_displacement(tn, dt, d_0, d_n)
+        d1 = parallel_explicit_solver_dis_pre(LocalK, g["F_rankwise"], Points, nodes, g["local_dirichlet"], Time,
+                                              elas, g["l_M"], 0.5, 1, 0, MODEL=False)
+        assert d1 is not d_0 and d1.shape == d_0.shape
+        d_n, d_0, tn = d_0, d1, tn + dt
+        if i + 1 in (1, 10, 100):
+            assert rel_l2(d1[:, 0], traj[f"step_{i + 1}"]) < noise_bound(i + 1)
