@@ -53,7 +53,7 @@ def build_rank_solver(mesh, n_parts, rank, device, block_nodes=0, threads=0):
     return sol, lay, gshared, dt
 
 
-def cpu_baseline_and_parity(sample_n=8, steps=300):
+def cpu_baseline_and_parity(sample_n=10, steps=12000):
     """Oracle (CPU port of the reference's per-step operations) timed on a bounded sample; the GPU steps the
     same sample for the parity figure."""
     from oracle import fem_oracle as fo
