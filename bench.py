@@ -90,10 +90,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5000)
     ap.add_argument("--warmup", type=int, default=500)
-    ap.add_argument("--n", type=int, default=0, help="override mesh refinement (25n x n x n cubes)")
+    ap.add_argument("--refine", type=int, default=0, help="override mesh refinement n (25n x n x n cubes)")
     ap.add_argument("--block-nodes", type=int, default=0)
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="process-group backend for N > 1 (nccl = RCCL)")
+    ap.add_argument("--same-device", action="store_true",
+                    help="rehearsal on a one-GPU box: every rank uses cuda:0 (needs --backend gloo)")
     args = ap.parse_args()
 
     import torch
@@ -104,13 +107,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if args.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
 
     from synchronization_avoiding_algorithms_amd.mesh import structured_beam
 
-    n = args.n or N_FOR_GPUS.get(world, int(round((world * 1028850 / 150.0) ** (1 / 3))))
+    n = args.refine or N_FOR_GPUS.get(world, int(round((world * 1028850 / 150.0) ** (1 / 3))))
     mesh = structured_beam(n)
     ne_total, nn_total = len(mesh.tets), len(mesh.points)
     sol, lay, gshared, dt = build_rank_solver(mesh, world, rank, local_rank, args.block_nodes, args.threads)

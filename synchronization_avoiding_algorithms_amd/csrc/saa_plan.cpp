@@ -60,6 +60,7 @@ struct Rcb {
 // free in that half.  If the scan window runs dry the cheapest clash is taken (a clash on an owned
 // vertex costs a read and an atomic, on a halo vertex only a read).
 // Returns through mult_sum / mult_cnt the worst bank multiplicity summed over (half, slot).
+double g_atomic_mult_sum = 0.0;  // debug statistic (SAA_PLAN_DEBUG)
 constexpr int kEvenPerms[12][4] = {{0, 1, 2, 3}, {0, 2, 3, 1}, {0, 3, 1, 2}, {1, 0, 3, 2}, {1, 2, 0, 3}, {1, 3, 2, 0},
                                    {2, 0, 1, 3}, {2, 1, 3, 0}, {2, 3, 0, 1}, {3, 0, 2, 1}, {3, 1, 0, 2}, {3, 2, 1, 0}};
 
@@ -135,6 +136,7 @@ void reorder_for_lds(std::vector<uint16_t> &conn, int64_t off, int32_t n_elem, i
             }
           }
         }
+        if (getenv("SAA_PLAN_DEBUG3")) fprintf(stderr, "  pass2 lane %d cost %d (max %d %d %d %d)\n", placed, best_k, max_all[0], max_all[1], max_all[2], max_all[3]);
         const uint16_t *c = src + 4 * static_cast<size_t>(pool[best_p]);
         for (int a = 0; a < 4; ++a) {
           const uint16_t v = c[kEvenPerms[best_q][a]];
@@ -145,15 +147,21 @@ void reorder_for_lds(std::vector<uint16_t> &conn, int64_t off, int32_t n_elem, i
       }
     }
     pool.erase(std::remove(pool.begin(), pool.begin() + lim, -1), pool.begin() + lim);
-    // quality of this half
+    // quality of this half: worst multiplicity seen by the reads (all lanes) and by the atomics (owned lanes)
     for (int a = 0; a < 4; ++a) {
-      int cnt[32] = {0};
-      int worst = 0;
-      for (int32_t l = 0; l < cap; ++l)
-        worst = std::max(worst, ++cnt[scratch[4 * static_cast<size_t>(out - cap + l) + a] & 31]);
+      int cnt[32] = {0}, cnt_o[32] = {0};
+      int worst = 0, worst_o = 0;
+      for (int32_t l = 0; l < cap; ++l) {
+        const uint16_t v = scratch[4 * static_cast<size_t>(out - cap + l) + a];
+        worst = std::max(worst, ++cnt[v & 31]);
+        if (v < owned_limit) worst_o = std::max(worst_o, ++cnt_o[v & 31]);
+      }
       mult_sum += worst;
+      g_atomic_mult_sum += worst_o;
       ++mult_cnt;
+      if (getenv("SAA_PLAN_DEBUG2")) fprintf(stderr, "%s%d/%d", a ? " " : "half: ", worst, worst_o);
     }
+    if (getenv("SAA_PLAN_DEBUG2")) fprintf(stderr, "  (cap %d, pool left %zu)\n", cap, pool.size());
   }
   std::copy(scratch.begin(), scratch.end(), conn.begin() + 4 * off);
 }
@@ -298,6 +306,10 @@ bool build_once(int32_t n_nodes, int32_t n_elems, const double *xyz, const int32
     plan.n_halo_total += d.n_halo;
   }
   plan.lds_conflict_factor = mult_cnt ? mult_sum / mult_cnt : 1.0;
+  if (getenv("SAA_PLAN_DEBUG"))
+    fprintf(stderr, "plan: read conflict factor %.3f, atomic conflict factor %.3f\n", plan.lds_conflict_factor,
+            mult_cnt ? g_atomic_mult_sum / mult_cnt : 1.0);
+  g_atomic_mult_sum = 0.0;
   return true;
 }
 

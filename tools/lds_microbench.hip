@@ -40,7 +40,11 @@ __global__ void bench(const int *__restrict__ idx, double *out, int n_slots, lon
         lds[my[j]] += v;
       }
     }
-    if (MODE == 1 || MODE == 2) v += acc * 1e-30;
+    if (MODE == 1 || MODE == 2) {
+      v += acc * 1e-30;
+#pragma unroll
+      for (int j = 0; j < kUnroll; ++j) my[j] = (my[j] + 64) & (n_slots - 1);  // same bank, new address: no hoisting
+    }
   }
   long long t1 = clock64();
   __syncthreads();
