@@ -97,13 +97,14 @@ int pick_threads(const saa::Plan &plan, int requested) {
   if (requested > 0) return requested;
   int max_elem = 0;
   for (const auto &b : plan.blocks) max_elem = std::max(max_elem, b.n_elem);
+  if (max_elem >= 4096) return 1024;
   if (max_elem >= 2048) return 512;
   if (max_elem >= 512) return 256;
   if (max_elem >= 128) return 128;
   return 64;
 }
 
-int lds_bytes_of(const saa::Plan &plan) { return saa::lds_bytes_for(plan.max_local); }
+int lds_bytes_of(const saa::Plan &plan) { return saa::lds_bytes_for(plan.max_local, plan.max_owned); }
 
 void fill_stats(const saa::Plan &plan, int lds, int threads, saa_plan_stats *out) {
   out->n_blocks = static_cast<int32_t>(plan.blocks.size());
@@ -118,10 +119,11 @@ void fill_stats(const saa::Plan &plan, int lds, int threads, saa_plan_stats *out
 
 bool build_fitting_plan(int32_t n_nodes, int32_t n_elems, const double *xyz, const int32_t *tets,
                         int32_t block_nodes, saa::Plan &plan, std::string &err) {
-  int32_t bn = block_nodes > 0 ? block_nodes : saa::kDefaultBlockNodes;
+  int32_t bn = block_nodes;  // <= 0: automatic (saa_plan.cpp)
   while (true) {
     if (!saa::build_plan(n_nodes, n_elems, xyz, tets, bn, plan, err)) return false;
     if (lds_bytes_of(plan) <= kLdsBudget) return true;
+    if (bn <= 0) bn = std::max(plan.max_owned, 16);
     if (bn <= 8) {
       err = "node blocks do not fit the 160 KiB LDS budget";
       return false;
@@ -328,6 +330,7 @@ int saa_create(const saa_problem *pb, saa_solver **out) {
   s->mesh.n_nodes = n;
   s->mesh.max_local = plan.max_local;
   s->mesh.max_owned = plan.max_owned;
+  s->mesh.force_stride = saa::force_stride_for(plan.max_owned);
   s->shared.node = s->sh_node.p;
   s->shared.slot = s->sh_slot.p;
   s->shared.foreign_slot = s->sh_foreign.p;

@@ -20,7 +20,7 @@ struct DeviceMesh {
   const double *fext;  // (3 n_nodes) un-ramped
   const int32_t *tag;  // (n_nodes)
   double lambda_, mu;
-  int32_t n_blocks, n_nodes, max_local, max_owned;
+  int32_t n_blocks, n_nodes, max_local, max_owned, force_stride;
 };
 
 // Scalars of one step, pre-computed on the host exactly as Python evaluates them

@@ -112,53 +112,59 @@ __device__ __forceinline__ void lds_barrier() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
-// LDS image (saa_plan.h): tiles of 288 nodes x 9 planes; plane stride 288 doubles = 2304 B.
-constexpr int kPlane = kTileNodes;             // doubles between two planes of one node
-constexpr int kAccPlane = 6 * kTileNodes;      // first force plane
-__device__ __forceinline__ int lds_slot(int local_node) {
-  const int t = local_node / kTileNodes;
-  return t * kTileDoubles + (local_node - t * kTileNodes);
-}
-
-// One element: connectivity holds the LDS slots of its 4 nodes; six ds_read_b64 per node (all in the
-// node's own bank pair), nodal forces, ds_add_f64 into the force planes of OWNED nodes.
+// One element: connectivity holds the block-local indices of its 4 nodes; three ds_read_b128 per node
+// record (48 B), nodal forces, ds_add_f64 into the force planes of OWNED nodes (LDS image: saa_plan.h).
 template <int ABLATE>
-__device__ __forceinline__ void element_forces(const ushort4 c, double *img, int owned_limit, double lam,
-                                               double mu, int tid, double &sink) {
-  const double *p0 = img + c.x, *p1 = img + c.y, *p2 = img + c.z, *p3 = img + c.w;
-  if (ABLATE == 2) {  // every lane reads its own fixed slots: no index-dependent LDS traffic
-    p0 = img + (tid & 63); p1 = p0 + 64; p2 = p0 + 128; p3 = p0 + 192;
+__device__ __forceinline__ void element_forces(const ushort4 c, const double *rec, double *acc, int fstride,
+                                               int n_owned, double lam, double mu, int tid, double &sink) {
+  const double2 *r0 = reinterpret_cast<const double2 *>(rec + 6 * c.x);
+  const double2 *r1 = reinterpret_cast<const double2 *>(rec + 6 * c.y);
+  const double2 *r2 = reinterpret_cast<const double2 *>(rec + 6 * c.z);
+  const double2 *r3 = reinterpret_cast<const double2 *>(rec + 6 * c.w);
+  if (ABLATE == 2) {  // every lane reads its own fixed records: no index-dependent LDS traffic
+    r0 = reinterpret_cast<const double2 *>(rec + 6 * (tid & 63)); r1 = r0 + 3; r2 = r0 + 6; r3 = r0 + 9;
   }
   Vec3 f1, f2, f3;
-  tet_forces({p0[0], p0[kPlane], p0[2 * kPlane]}, {p1[0], p1[kPlane], p1[2 * kPlane]},
-             {p2[0], p2[kPlane], p2[2 * kPlane]}, {p3[0], p3[kPlane], p3[2 * kPlane]},
-             {p0[3 * kPlane], p0[4 * kPlane], p0[5 * kPlane]}, {p1[3 * kPlane], p1[4 * kPlane], p1[5 * kPlane]},
-             {p2[3 * kPlane], p2[4 * kPlane], p2[5 * kPlane]}, {p3[3 * kPlane], p3[4 * kPlane], p3[5 * kPlane]},
-             lam, mu, f1, f2, f3);
+  if (ABLATE == 6) {  // VALU only: operands from registers, result to a register sink
+    const double t = 1.0 + 1e-3 * tid + sink;
+    tet_forces({t, 0.1, 0.2}, {1.1 * t, 0.3, 0.1}, {0.2, t, 0.3}, {0.1, 0.2, 1.3 * t}, {t, t, 0}, {0, t, t}, {t, 0, t},
+               {t, t, t}, lam, mu, f1, f2, f3);
+    sink += f1.x + f1.y + f1.z + f2.x + f2.y + f2.z + f3.x + f3.y + f3.z;
+    return;
+  }
+  const double2 a0 = r0[0], b0 = r0[1], c0 = r0[2], a1 = r1[0], b1 = r1[1], c1 = r1[2];
+  const double2 a2 = r2[0], b2 = r2[1], c2 = r2[2], a3 = r3[0], b3 = r3[1], c3 = r3[2];
+  if (ABLATE == 7) {  // LDS only: reads and atomics without the element arithmetic
+    f1 = {a0.x + a1.y, a0.y + a2.x, b0.x + a3.x};
+    f2 = {b1.x + b0.y, a2.y + c0.x, b2.x + c0.y};
+    f3 = {a3.y + b1.y + c1.x + c1.y, b3.x + b2.y + c2.x + c2.y, b3.y + c3.x + c3.y};
+  } else {
+    tet_forces({a0.x, a0.y, b0.x}, {a1.x, a1.y, b1.x}, {a2.x, a2.y, b2.x}, {a3.x, a3.y, b3.x},
+               {b0.y, c0.x, c0.y}, {b1.y, c1.x, c1.y}, {b2.y, c2.x, c2.y}, {b3.y, c3.x, c3.y}, lam, mu, f1, f2, f3);
+  }
   if (ABLATE == 1) {
     sink += f1.x + f1.y + f1.z + f2.x + f2.y + f2.z + f3.x + f3.y + f3.z;
     return;
   }
-  double *acc = img + kAccPlane;
-  if (c.x < owned_limit) {
+  if (c.x < n_owned) {
     lds_add(acc + c.x, -(f1.x + f2.x + f3.x));
-    lds_add(acc + c.x + kPlane, -(f1.y + f2.y + f3.y));
-    lds_add(acc + c.x + 2 * kPlane, -(f1.z + f2.z + f3.z));
+    lds_add(acc + c.x + fstride, -(f1.y + f2.y + f3.y));
+    lds_add(acc + c.x + 2 * fstride, -(f1.z + f2.z + f3.z));
   }
-  if (c.y < owned_limit) {
+  if (c.y < n_owned) {
     lds_add(acc + c.y, f1.x);
-    lds_add(acc + c.y + kPlane, f1.y);
-    lds_add(acc + c.y + 2 * kPlane, f1.z);
+    lds_add(acc + c.y + fstride, f1.y);
+    lds_add(acc + c.y + 2 * fstride, f1.z);
   }
-  if (c.z < owned_limit) {
+  if (c.z < n_owned) {
     lds_add(acc + c.z, f2.x);
-    lds_add(acc + c.z + kPlane, f2.y);
-    lds_add(acc + c.z + 2 * kPlane, f2.z);
+    lds_add(acc + c.z + fstride, f2.y);
+    lds_add(acc + c.z + 2 * fstride, f2.z);
   }
-  if (c.w < owned_limit) {
+  if (c.w < n_owned) {
     lds_add(acc + c.w, f3.x);
-    lds_add(acc + c.w + kPlane, f3.y);
-    lds_add(acc + c.w + 2 * kPlane, f3.z);
+    lds_add(acc + c.w + fstride, f3.y);
+    lds_add(acc + c.w + 2 * fstride, f3.z);
   }
 }
 
@@ -179,7 +185,9 @@ __global__ void fused_step_kernel(DeviceMesh m, const double *__restrict__ d0, c
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const BlockDesc bd = m.blocks[plan_block(blockIdx.x, m.n_blocks)];
   const int tid = threadIdx.x, nt = blockDim.x;
-  double *img = lds;  // tiled node image, see saa_plan.h
+  double *rec = lds;                       // [n_owned + n_halo][6]: x y z ux uy uz
+  double *acc = lds + 6 * m.max_local;     // force planes fx | fy | fz, each m.force_stride doubles
+  const int fstride = m.force_stride;
   const int n_own3 = 3 * bd.n_owned, n_halo3 = 3 * bd.n_halo;
   const int64_t base = 3 * (int64_t)bd.node_start;
   const int32_t *hid = m.halo_ids + bd.halo_off;
@@ -206,10 +214,9 @@ __global__ void fused_step_kernel(DeviceMesh m, const double *__restrict__ d0, c
     const double *uo = d0 + base;
     for (int i = tid; i < n_own3; i += nt) {
       const int n = i / 3, c = i - 3 * n;
-      double *p = img + lds_slot(n) + c * kPlane;
-      p[0] = ABLATE == 3 ? 1.0 * i : xo[i];
-      p[3 * kPlane] = ABLATE == 3 ? 1e-3 * i : uo[i];
-      p[kAccPlane] = 0.0;
+      rec[6 * n + c] = ABLATE == 3 ? 1.0 * i : xo[i];
+      rec[6 * n + 3 + c] = ABLATE == 3 ? 1e-3 * i : uo[i];
+      acc[n + c * fstride] = 0.0;
     }
   }
 
@@ -240,10 +247,22 @@ __global__ void fused_step_kernel(DeviceMesh m, const double *__restrict__ d0, c
 #pragma unroll
     for (int j = 0; j < kPreConn; ++j)
       if (tid + j * nt < bd.n_interior)
-        element_forces<ABLATE>(cpre[j], img, bd.owned_limit, m.lambda_, m.mu, tid, sink);
-    for (int e = tid + kPreConn * nt; e < bd.n_interior; e += nt)
-      element_forces<ABLATE>(conn[e], img, bd.owned_limit, m.lambda_, m.mu, tid, sink);
+        element_forces<ABLATE>(cpre[j], rec, acc, fstride, bd.n_owned, m.lambda_, m.mu, tid, sink);
+    // (rare) further interior sweeps, software-pipelined: the next connectivity entry is in flight while
+    // the current element computes - a dependent global load per sweep would expose its L2 latency
+    if (tid + kPreConn * nt < bd.n_interior) {
+      const int last = bd.n_elem - 1;
+      ushort4 cur = conn[tid + kPreConn * nt];
+      for (int e = tid + kPreConn * nt; e < bd.n_interior; e += nt) {
+        const ushort4 nxt = conn[min(e + nt, last)];
+        element_forces<ABLATE>(cur, rec, acc, fstride, bd.n_owned, m.lambda_, m.mu, tid, sink);
+        cur = nxt;
+      }
+    }
   }
+  // first boundary sweep's connectivity: issued now, consumed after the halo records are in LDS
+  const int e_b0 = bd.n_interior + tid;
+  ushort4 bcur = conn[min(e_b0, max(bd.n_elem - 1, 0))];
 
   // ---- 4. halo records -> LDS --------------------------------------------------------------------
 #pragma unroll
@@ -251,28 +270,31 @@ __global__ void fused_step_kernel(DeviceMesh m, const double *__restrict__ d0, c
     const int i = tid + j * nt;
     if (i < n_halo3) {
       const int n = i / 3, c = i - 3 * n;
-      double *p = img + lds_slot(bd.n_owned + n) + c * kPlane;
-      p[0] = hx[j];
-      p[3 * kPlane] = hu[j];
+      rec[6 * (bd.n_owned + n) + c] = hx[j];
+      rec[6 * (bd.n_owned + n) + 3 + c] = hu[j];
     }
   }
   for (int i = tid + kPreHalo * nt; i < n_halo3; i += nt) {  // blocks with more halo than the prefetch depth
     const int n = i / 3, c = i - 3 * n;
     const int64_t g = 3 * (int64_t)hid[n] + c;
-    double *p = img + lds_slot(bd.n_owned + n) + c * kPlane;
-    p[0] = m.xyz[g];
-    p[3 * kPlane] = d0[g];
+    rec[6 * (bd.n_owned + n) + c] = m.xyz[g];
+    rec[6 * (bd.n_owned + n) + 3 + c] = d0[g];
   }
   lds_barrier();
 
   // ---- 5. boundary elements (at least one halo node) ----------------------------------------------
-  if (ABLATE != 5)
-    for (int e = bd.n_interior + tid; e < bd.n_elem; e += nt)
-      element_forces<ABLATE>(conn[e], img, bd.owned_limit, m.lambda_, m.mu, tid, sink);
-  if (ABLATE == 1 && sink == 12345.678) img[kAccPlane] = sink;
+  if (ABLATE != 5) {
+    const int last = bd.n_elem - 1;
+    for (int e = e_b0; e < bd.n_elem; e += nt) {
+      const ushort4 nxt = conn[min(e + nt, last)];
+      element_forces<ABLATE>(bcur, rec, acc, fstride, bd.n_owned, m.lambda_, m.mu, tid, sink);
+      bcur = nxt;
+    }
+  }
+  if ((ABLATE == 1 || ABLATE == 6) && sink == 12345.678) acc[0] = sink;
   lds_barrier();
   if (ABLATE == 4) {
-    if (tid == 0) out[base] = img[kAccPlane];
+    if (tid == 0) out[base] = acc[0];
     return;
   }
 
@@ -280,16 +302,15 @@ __global__ void fused_step_kernel(DeviceMesh m, const double *__restrict__ d0, c
   if (FORCE_ONLY) {
     for (int i = tid; i < n_own3; i += nt) {
       const int n = i / 3, c = i - 3 * n;
-      out[base + i] = img[lds_slot(n) + kAccPlane + c * kPlane];
+      out[base + i] = acc[n + c * fstride];
     }
     return;
   }
   auto finish = [&](int i, double mass, double fpre, double dnv, int32_t tag) {
     const int n = i / 3, c = i - 3 * n;
-    const double *p = img + lds_slot(n) + c * kPlane;
-    const double f = p[kAccPlane];
+    const double f = acc[n + c * fstride];
     if (iface != nullptr && (tag & kTagShared)) iface[3 * (int64_t)(tag >> kTagSlotShift) + c] = f;
-    double v = cd_update_dof(f, fpre, mass, p[3 * kPlane], dnv, k);
+    double v = cd_update_dof(f, fpre, mass, rec[6 * n + 3 + c], dnv, k);
     if (tag & (1 << c)) v = 0.0;  // d1[Local_Dirichlet] = 0   (Dynamic_solver.py:20)
     out[base + i] = v;
   };
@@ -397,7 +418,7 @@ void launch_fused_step_ablated(int variant, const DeviceMesh &m, int threads, in
                        dn, d1, none, k);                                                                   \
     break;
   switch (variant) {
-    SAA_ABL(0) SAA_ABL(1) SAA_ABL(2) SAA_ABL(3) SAA_ABL(4) SAA_ABL(5)
+    SAA_ABL(0) SAA_ABL(1) SAA_ABL(2) SAA_ABL(3) SAA_ABL(4) SAA_ABL(5) SAA_ABL(6) SAA_ABL(7)
     default: break;
   }
 #undef SAA_ABL

@@ -2,6 +2,8 @@
 #include "saa_plan.h"
 
 #include <algorithm>
+#include <atomic>
+#include <thread>
 #include <cstdio>
 #include <cstdlib>
 #include <cmath>
@@ -47,121 +49,131 @@ struct Rcb {
   }
 };
 
-// Re-order (and re-orient) the element copies of one block for the LDS traffic of the element phase.
-// Every per-node quantity lives in LDS bank pair (slot mod 32) (saa_plan.h, LDS image), and an LDS
-// wave-instruction (ds_read_b64 of one plane, ds_add_f64 of one force component) is executed per
-// vertex slot over two 32-lane halves; lanes of a half that share a bank pair are serialised, lanes
-// adding to the SAME address even more so (gfx950, tools/lds_microbench.hip: ds_add_f64 costs 7
-// cycles conflict-free, 22 for random nodes, 60 when 6 lanes hit one address - the natural order of
-// the 6 tets around a cube diagonal).
-// Packing, one half-wave (32 element slots) at a time: scan the not yet placed elements and take
-// those for which one of the 12 EVEN vertex permutations (orientation, hence signed detJ, is
-// preserved; the nodal forces follow their vertices) puts all four vertices on bank pairs still
-// free in that half.  If the scan window runs dry the cheapest clash is taken (a clash on an owned
-// vertex costs a read and an atomic, on a halo vertex only a read).
-// Returns through mult_sum / mult_cnt the worst bank multiplicity summed over (half, slot).
-double g_atomic_mult_sum = 0.0;  // debug statistic (SAA_PLAN_DEBUG)
+// Re-order (and re-orient) the element copies of one block for the LDS traffic of the element phase
+// (LDS image and bank rules: saa_plan.h).  Measured on gfx950 (tools/lds_microbench.hip): ds_add_f64 costs
+// 7 cycles per wave-instruction conflict-free, 22 for random nodes, 60 when 6 lanes hit one address (the
+// natural order of the 6 tets around a cube diagonal); ds_read_b128 6 conflict-free, 11 random.
+// Packing, one half-wave (32 element slots) at a time: scan the not yet placed elements and take those for
+// which one of the 12 EVEN vertex permutations (orientation, hence signed detJ, is preserved; the nodal
+// forces follow their vertices) and one of the half's two ds_read_b128 lane groups leaves every vertex on
+// a free bank: node mod 16 free in the group (reads), node mod 32 free in the half for owned vertices
+// (atomics).  When the scan window runs dry the placement that raises the worst multiplicities least is
+// taken.  mult_sum / mult_cnt accumulate the worst read multiplicity over (lane group, vertex slot).
 constexpr int kEvenPerms[12][4] = {{0, 1, 2, 3}, {0, 2, 3, 1}, {0, 3, 1, 2}, {1, 0, 3, 2}, {1, 2, 0, 3}, {1, 3, 2, 0},
                                    {2, 0, 1, 3}, {2, 1, 3, 0}, {2, 3, 0, 1}, {3, 0, 2, 1}, {3, 1, 0, 2}, {3, 2, 1, 0}};
+// ds_read_b128 lane groups of a 32-lane half (MI355X_MICROARCH.md, LDS): {0-3,12-15,20-27} and {4-11,16-19,28-31}
+constexpr int kGroupLanes[2][16] = {{0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27},
+                                    {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31}};
 
-void reorder_for_lds(std::vector<uint16_t> &conn, int64_t off, int32_t n_elem, int32_t owned_limit,
-                     std::vector<uint16_t> &scratch, double &mult_sum, int64_t &mult_cnt) {
+struct PackStats {
+  double read_mult = 0.0, atomic_mult = 0.0;  // sums of worst multiplicities
+  int64_t read_cnt = 0, atomic_cnt = 0;
+};
+
+void reorder_for_lds(std::vector<uint16_t> &conn, int64_t off, int32_t n_elem, int32_t n_owned,
+                     std::vector<uint16_t> &scratch, PackStats &st) {
   constexpr int kHalf = 32;
   constexpr int kWindow = 768;  // pool elements examined per half before clashes are accepted
   if (n_elem <= 0) return;
   const int32_t n_halves = (n_elem + kHalf - 1) / kHalf;
   std::vector<int32_t> pool(n_elem);
   for (int32_t e = 0; e < n_elem; ++e) pool[e] = e;
-  scratch.resize(4 * static_cast<size_t>(n_elem));
+  scratch.assign(4 * static_cast<size_t>(n_elem), 0);
   const uint16_t *src = &conn[4 * static_cast<size_t>(off)];
-  int32_t out = 0;
+  int32_t done = 0;
   for (int32_t h = 0; h < n_halves; ++h) {
-    const int32_t cap = std::min<int32_t>(kHalf, n_elem - out);
-    uint32_t taken[4] = {0, 0, 0, 0};
+    const int32_t cap = std::min<int32_t>(kHalf, n_elem - done);
+    // lanes available in this half: lane l exists if l < cap
+    int32_t free_lane[2][16], n_free[2] = {0, 0};
+    for (int g = 0; g < 2; ++g)
+      for (int j = 0; j < 16; ++j)
+        if (kGroupLanes[g][j] < cap) free_lane[g][n_free[g]++] = kGroupLanes[g][j];
+    int used[2] = {0, 0};
+    uint8_t cnt_rd[2][4][16] = {}, cnt_at[4][32] = {};
+    int max_rd[2][4] = {}, max_at[4] = {};
+    uint32_t taken_rd[2][4] = {}, taken_at[4] = {};
     int32_t placed = 0;
-    auto put = [&](int32_t pool_pos, int perm) {
+    auto put = [&](int32_t pool_pos, int perm, int g) {
       const uint16_t *c = src + 4 * static_cast<size_t>(pool[pool_pos]);
+      const int32_t lane = free_lane[g][used[g]++];
       for (int a = 0; a < 4; ++a) {
         const uint16_t v = c[kEvenPerms[perm][a]];
-        scratch[4 * static_cast<size_t>(out) + a] = v;
-        taken[a] |= 1u << (v & 31);
+        scratch[4 * static_cast<size_t>(done + lane) + a] = v;
+        taken_rd[g][a] |= 1u << (v & 15);
+        max_rd[g][a] = std::max<int>(max_rd[g][a], ++cnt_rd[g][a][v & 15]);
+        if (v < n_owned) {
+          taken_at[a] |= 1u << (v & 31);
+          max_at[a] = std::max<int>(max_at[a], ++cnt_at[a][v & 31]);
+        }
       }
-      ++out;
       ++placed;
       pool[pool_pos] = -1;
     };
-    // pass 1: clash-free placements
     const int32_t lim = std::min<int32_t>(static_cast<int32_t>(pool.size()), kWindow);
+    // pass 1: clash-free placements
     for (int32_t p = 0; p < lim && placed < cap; ++p) {
       const uint16_t *c = src + 4 * static_cast<size_t>(pool[p]);
-      const uint32_t r[4] = {c[0] & 31u, c[1] & 31u, c[2] & 31u, c[3] & 31u};
-      for (int q = 0; q < 12; ++q) {
+      bool ok = false;
+      for (int q = 0; q < 12 && !ok; ++q) {
         const int *pm = kEvenPerms[q];
-        if (((taken[0] >> r[pm[0]]) | (taken[1] >> r[pm[1]]) | (taken[2] >> r[pm[2]]) | (taken[3] >> r[pm[3]])) & 1u)
-          continue;
-        put(p, q);
-        break;
+        uint32_t at = 0;
+        for (int a = 0; a < 4; ++a)
+          if (c[pm[a]] < n_owned) at |= taken_at[a] >> (c[pm[a]] & 31);
+        if (at & 1u) continue;
+        for (int g = 0; g < 2 && !ok; ++g) {
+          if (used[g] >= n_free[g]) continue;
+          if (((taken_rd[g][0] >> (c[pm[0]] & 15)) | (taken_rd[g][1] >> (c[pm[1]] & 15)) |
+               (taken_rd[g][2] >> (c[pm[2]] & 15)) | (taken_rd[g][3] >> (c[pm[3]] & 15))) & 1u)
+            continue;
+          put(p, q, g);
+          ok = true;
+        }
       }
     }
-    // pass 2: fill the rest of the half where it hurts least.  An LDS instruction costs its WORST bank
-    // multiplicity, so once a slot has one doubled bank further doublings on other banks of that slot are
-    // free.  Reads (6 x ds_read_b64, ~2 cycles per level) see every vertex, atomics (3 x ds_add_f64, ~7
-    // cycles per level) only owned ones.
-    if (placed < cap) {
-      uint8_t cnt_all[4][32] = {}, cnt_own[4][32] = {};
-      int max_all[4] = {0, 0, 0, 0}, max_own[4] = {0, 0, 0, 0};
-      for (int32_t l = 0; l < placed; ++l)
-        for (int a = 0; a < 4; ++a) {
-          const uint16_t v = scratch[4 * static_cast<size_t>(out - placed + l) + a];
-          max_all[a] = std::max<int>(max_all[a], ++cnt_all[a][v & 31]);
-          if (v < owned_limit) max_own[a] = std::max<int>(max_own[a], ++cnt_own[a][v & 31]);
-        }
-      while (placed < cap) {
-        int32_t best_p = -1, best_q = 0, best_k = 1 << 30;
-        for (int32_t p = 0; p < lim && best_k > 0; ++p) {
-          if (pool[p] < 0) continue;
-          const uint16_t *c = src + 4 * static_cast<size_t>(pool[p]);
-          for (int q = 0; q < 12; ++q) {
-            int k = 0;
+    // pass 2: fill the rest where it raises the worst multiplicities least (an LDS instruction costs its
+    // WORST bank multiplicity; reads 3 x ds_read_b128 per vertex ~4 cycles a level, atomics 3 x ds_add_f64 ~7)
+    while (placed < cap) {
+      int32_t best_p = -1, best_q = 0, best_g = 0, best_k = 1 << 30;
+      for (int32_t p = 0; p < lim && best_k > 0; ++p) {
+        if (pool[p] < 0) continue;
+        const uint16_t *c = src + 4 * static_cast<size_t>(pool[p]);
+        for (int q = 0; q < 12 && best_k > 0; ++q) {
+          int k_at = 0;
+          for (int a = 0; a < 4; ++a) {
+            const uint16_t v = c[kEvenPerms[q][a]];
+            if (v < n_owned && cnt_at[a][v & 31] + 1 > max_at[a]) k_at += 21;
+          }
+          for (int g = 0; g < 2; ++g) {
+            if (used[g] >= n_free[g]) continue;
+            int k = k_at;
             for (int a = 0; a < 4; ++a) {
               const uint16_t v = c[kEvenPerms[q][a]];
-              if (cnt_all[a][v & 31] + 1 > max_all[a]) k += 12;
-              if (v < owned_limit && cnt_own[a][v & 31] + 1 > max_own[a]) k += 21;
+              if (cnt_rd[g][a][v & 15] + 1 > max_rd[g][a]) k += 12;
             }
             if (k < best_k) {
               best_k = k;
               best_p = p;
               best_q = q;
-              if (k == 0) break;
+              best_g = g;
             }
           }
         }
-        if (getenv("SAA_PLAN_DEBUG3")) fprintf(stderr, "  pass2 lane %d cost %d (max %d %d %d %d)\n", placed, best_k, max_all[0], max_all[1], max_all[2], max_all[3]);
-        const uint16_t *c = src + 4 * static_cast<size_t>(pool[best_p]);
-        for (int a = 0; a < 4; ++a) {
-          const uint16_t v = c[kEvenPerms[best_q][a]];
-          max_all[a] = std::max<int>(max_all[a], ++cnt_all[a][v & 31]);
-          if (v < owned_limit) max_own[a] = std::max<int>(max_own[a], ++cnt_own[a][v & 31]);
-        }
-        put(best_p, best_q);
       }
+      put(best_p, best_q, best_g);
     }
     pool.erase(std::remove(pool.begin(), pool.begin() + lim, -1), pool.begin() + lim);
-    // quality of this half: worst multiplicity seen by the reads (all lanes) and by the atomics (owned lanes)
     for (int a = 0; a < 4; ++a) {
-      int cnt[32] = {0}, cnt_o[32] = {0};
-      int worst = 0, worst_o = 0;
-      for (int32_t l = 0; l < cap; ++l) {
-        const uint16_t v = scratch[4 * static_cast<size_t>(out - cap + l) + a];
-        worst = std::max(worst, ++cnt[v & 31]);
-        if (v < owned_limit) worst_o = std::max(worst_o, ++cnt_o[v & 31]);
+      for (int g = 0; g < 2; ++g)
+        if (n_free[g] > 0) {
+          st.read_mult += max_rd[g][a];
+          ++st.read_cnt;
+        }
+      if (max_at[a] > 0) {
+        st.atomic_mult += max_at[a];
+        ++st.atomic_cnt;
       }
-      mult_sum += worst;
-      g_atomic_mult_sum += worst_o;
-      ++mult_cnt;
-      if (getenv("SAA_PLAN_DEBUG2")) fprintf(stderr, "%s%d/%d", a ? " " : "half: ", worst, worst_o);
     }
-    if (getenv("SAA_PLAN_DEBUG2")) fprintf(stderr, "  (cap %d, pool left %zu)\n", cap, pool.size());
+    done += cap;
   }
   std::copy(scratch.begin(), scratch.end(), conn.begin() + 4 * off);
 }
@@ -173,6 +185,18 @@ int32_t choose_block_count(int32_t n_nodes, int32_t block_nodes) {
   if (nb > 192) nb = (nb + 255) / 256 * 256;
   nb = std::max<int64_t>(1, std::min<int64_t>(nb, n_nodes));
   return static_cast<int32_t>(nb);
+}
+
+// Automatic block size.  Up to ~190k nodes (one MI355X-sized partition of ~1M tets) every CU gets exactly
+// ONE block: fewer, larger blocks duplicate fewer border elements (1.25x at 744 owned nodes against
+// 1.37x at 372) and all 256 run as one wave of workgroups of 1024 threads.  Larger partitions use
+// 384-node blocks in several rounds per CU, which overlap each other's memory and LDS phases
+// (measured: 8.2M tets 121 us/step with 377-node blocks against 142 us with 707-node blocks).
+int32_t auto_block_nodes(int32_t n_nodes) {
+  constexpr int32_t kCUs = 256, kBig = 760;
+  if (n_nodes <= kDefaultBlockNodes) return n_nodes;  // tiny mesh: one block
+  if (n_nodes <= kCUs * kBig) return std::max<int32_t>(96, (n_nodes + kCUs - 1) / kCUs);
+  return kDefaultBlockNodes;
 }
 
 bool build_once(int32_t n_nodes, int32_t n_elems, const double *xyz, const int32_t *tets,
@@ -238,8 +262,6 @@ bool build_once(int32_t n_nodes, int32_t n_elems, const double *xyz, const int32
   std::vector<int32_t> tmp;
   std::vector<uint16_t> reorder_scratch;
   std::vector<char> interior_flag;
-  double mult_sum = 0.0;
-  int64_t mult_cnt = 0;
   for (int32_t b = 0; b < n_blocks; ++b) {
     BlockDesc &d = plan.blocks[b];
     d.node_start = block_start[b];
@@ -293,23 +315,42 @@ bool build_once(int32_t n_nodes, int32_t n_elems, const double *xyz, const int32
       (void)hi_i;
       interior_flag.clear();
     }
-    d.owned_limit = lds_index(d.n_owned);
-    // connectivity becomes LDS slots (tile/plane layout of saa_plan.h); slot mod 32 = bank pair
-    for (int64_t c = 4 * off[b]; c < 4 * off[b + 1]; ++c)
-      plan.conn[c] = static_cast<uint16_t>(lds_index(plan.conn[c]));
-    reorder_for_lds(plan.conn, off[b], d.n_interior, d.owned_limit, reorder_scratch, mult_sum, mult_cnt);
-    reorder_for_lds(plan.conn, off[b] + d.n_interior, d.n_elem - d.n_interior, d.owned_limit, reorder_scratch,
-                    mult_sum, mult_cnt);
+    d.pad_ = 0;
     plan.halo_ids.insert(plan.halo_ids.end(), tmp.begin(), tmp.end());
     plan.max_owned = std::max(plan.max_owned, d.n_owned);
     plan.max_local = std::max(plan.max_local, d.n_owned + d.n_halo);
     plan.n_halo_total += d.n_halo;
   }
-  plan.lds_conflict_factor = mult_cnt ? mult_sum / mult_cnt : 1.0;
-  if (getenv("SAA_PLAN_DEBUG"))
-    fprintf(stderr, "plan: read conflict factor %.3f, atomic conflict factor %.3f\n", plan.lds_conflict_factor,
-            mult_cnt ? g_atomic_mult_sum / mult_cnt : 1.0);
-  g_atomic_mult_sum = 0.0;
+  // LDS packing of every block's interior and boundary element lists: independent per block -> threads
+  {
+    const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    const unsigned n_thr = static_cast<unsigned>(std::min<int64_t>(hw, std::max<int32_t>(1, n_blocks / 8)));
+    std::vector<PackStats> stats(n_thr);
+    std::atomic<int32_t> next{0};
+    auto work = [&](unsigned t) {
+      std::vector<uint16_t> scratch;
+      for (int32_t b = next.fetch_add(1); b < n_blocks; b = next.fetch_add(1)) {
+        const BlockDesc &d = plan.blocks[b];
+        reorder_for_lds(plan.conn, off[b], d.n_interior, d.n_owned, scratch, stats[t]);
+        reorder_for_lds(plan.conn, off[b] + d.n_interior, d.n_elem - d.n_interior, d.n_owned, scratch, stats[t]);
+      }
+    };
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < n_thr; ++t) pool.emplace_back(work, t);
+    work(0);
+    for (auto &th : pool) th.join();
+    PackStats tot;
+    for (const auto &st : stats) {
+      tot.read_mult += st.read_mult;
+      tot.read_cnt += st.read_cnt;
+      tot.atomic_mult += st.atomic_mult;
+      tot.atomic_cnt += st.atomic_cnt;
+    }
+    plan.lds_conflict_factor = tot.read_cnt ? tot.read_mult / tot.read_cnt : 1.0;
+    if (getenv("SAA_PLAN_DEBUG"))
+      fprintf(stderr, "plan: read conflict factor %.3f, atomic conflict factor %.3f (%u threads)\n",
+              plan.lds_conflict_factor, tot.atomic_cnt ? tot.atomic_mult / tot.atomic_cnt : 1.0, n_thr);
+  }
   return true;
 }
 
@@ -332,7 +373,7 @@ bool build_plan(int32_t n_nodes, int32_t n_elems, const double *xyz, const int32
       err = "build_plan: non-finite coordinate at node " + std::to_string(i / 3);
       return false;
     }
-  int32_t bn = block_nodes > 0 ? block_nodes : kDefaultBlockNodes;
+  int32_t bn = block_nodes > 0 ? block_nodes : auto_block_nodes(n_nodes);
   bn = std::min(bn, kMaxLocalNodes);
   while (true) {
     bool too_big = false;

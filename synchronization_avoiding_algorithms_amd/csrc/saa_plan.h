@@ -21,23 +21,19 @@ struct BlockDesc {
   int32_t elem_off;    // offset into conn (element copies)
   int32_t n_elem;
   int32_t n_interior;  // elements [0,n_interior) touch owned nodes only; the rest need halo records
-  int32_t owned_limit; // lds_index(n_owned): connectivity entries below it refer to owned nodes
+  int32_t pad_;
 };
 
-// LDS image of a block: tiles of kTileNodes nodes, each tile 9 planes (x y z ux uy uz fx fy fz) of
-// kTileNodes doubles.  Plane stride = 288 doubles = 2304 B = 9 * 256 B: (a) a multiple of the 256-B
-// bank row, so every plane of a node sits in the same LDS bank pair (slot mod 32) and ONE ordering
-// criterion makes record reads and force atomics conflict-free; (b) beyond the reach of
-// ds_read2_b64 (8-bit offsets of 8 B) and not a multiple of 512 B (ds_read2st64_b64), so hipcc keeps
-// the full-rate ds_read_b64 instead of pairing planes into half-rate two-address reads.
-constexpr int32_t kTileNodes = 288;
-constexpr int32_t kTilePlanes = 9;
-constexpr int32_t kTileDoubles = kTileNodes * kTilePlanes;  // 2592 (= 81 * 32: tiles keep the bank phase)
-inline int32_t lds_index(int32_t local_node) {
-  return (local_node / kTileNodes) * kTileDoubles + (local_node % kTileNodes);
-}
-inline int32_t lds_bytes_for(int32_t max_local) {
-  return ((max_local + kTileNodes - 1) / kTileNodes) * kTileDoubles * 8;
+// LDS image of a block (doubles): node records [n_local][6] = x y z ux uy uz (48 B, 16-B aligned: three
+// ds_read_b128 per node), then three force planes fx[], fy[], fz[] of `force_stride` doubles (multiple of 32,
+// so that the plane of a node sits in bank pair (node mod 32) for every component).
+//   * ds_read_b128 is executed per 16-lane group; lanes of a group collide unless their nodes differ mod 16
+//     (record start bank = 12*node mod 64 takes 16 distinct values);
+//   * ds_add_f64 is executed per 32-lane half; lanes collide unless their nodes differ mod 32.
+// The plan packs elements so that both hold as far as possible (reorder_for_lds).
+inline int32_t force_stride_for(int32_t max_owned) { return (max_owned + 31) / 32 * 32; }
+inline int32_t lds_bytes_for(int32_t max_local, int32_t max_owned) {
+  return 8 * (6 * max_local + 3 * force_stride_for(max_owned));
 }
 
 struct Plan {
@@ -46,7 +42,7 @@ struct Plan {
   std::vector<int32_t> old_to_new;
   std::vector<BlockDesc> blocks;
   std::vector<int32_t> halo_ids;    // internal node ids, per block sorted ascending
-  std::vector<uint16_t> conn;       // 4 LDS indices (lds_index of the block-local node) per element copy
+  std::vector<uint16_t> conn;       // 4 block-local node indices per element copy (owned nodes first)
   double lds_conflict_factor = 1.0; // mean over (half-wave, vertex slot) of the worst bank multiplicity
   int32_t max_owned = 0, max_local = 0;
   int64_t n_elem_copies = 0, n_halo_total = 0;
@@ -54,7 +50,7 @@ struct Plan {
 
 // Largest number of block-local nodes (owned + halo) a workgroup may stage; bounded by the 16-bit
 // local indices and by the LDS budget the kernels are compiled for.
-constexpr int32_t kMaxLocalNodes = 2016;  // 7 tiles * 20.25 KiB = 141.75 KiB of LDS
+constexpr int32_t kMaxLocalNodes = 2730;  // 2730 * 48 B = 128 KiB of node records
 constexpr int32_t kDefaultBlockNodes = 384;
 
 // Builds the plan; on failure returns false and fills err.  block_nodes <= 0 selects the default.
