@@ -96,7 +96,7 @@ namespace {
 int pick_threads(const saa::Plan &plan, int requested) {
   if (requested > 0) return requested;
   int max_elem = 0;
-  for (const auto &b : plan.blocks) max_elem = std::max(max_elem, b.n_elem);
+  for (const auto &b : plan.blocks) max_elem = std::max(max_elem, 2 * b.n_elem);  // items ~ pairs
   if (max_elem >= 4096) return 1024;
   if (max_elem >= 2048) return 512;
   if (max_elem >= 512) return 256;
@@ -298,7 +298,7 @@ int saa_create(const saa_problem *pb, saa_solver **out) {
     std::vector<int32_t> halo_padded(plan.halo_ids);
     halo_padded.push_back(0);
     std::vector<uint16_t> conn_padded(plan.conn);
-    conn_padded.insert(conn_padded.end(), 4, 0);
+    conn_padded.insert(conn_padded.end(), 8, 0);
     CREATE_TRY(s->halo_ids.upload(halo_padded));
     CREATE_TRY(s->conn.upload(conn_padded));
   }
@@ -319,7 +319,7 @@ int saa_create(const saa_problem *pb, saa_solver **out) {
 
   s->mesh.blocks = s->blocks.p;
   s->mesh.halo_ids = s->halo_ids.p;
-  s->mesh.conn = reinterpret_cast<const ushort4 *>(s->conn.p);
+  s->mesh.conn = reinterpret_cast<const uint4 *>(s->conn.p);
   s->mesh.xyz = s->xyz.p;
   s->mesh.mass = s->mass.p;
   s->mesh.fext = s->fext.p;

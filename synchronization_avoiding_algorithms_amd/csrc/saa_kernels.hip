@@ -19,6 +19,10 @@
 
 #include "saa_device.h"
 
+#ifndef SAA_LB
+#define SAA_LB 1024
+#endif
+
 namespace saa {
 
 // ---------------------------------------------------------------------------------------------
@@ -112,75 +116,111 @@ __device__ __forceinline__ void lds_barrier() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
-// One element: connectivity holds the block-local indices of its 4 nodes; three ds_read_b128 per node
-// record (48 B), nodal forces, ds_add_f64 into the force planes of OWNED nodes (LDS image: saa_plan.h).
-template <int ABLATE>
-__device__ __forceinline__ void element_forces(const ushort4 c, const double *rec, double *acc, int fstride,
-                                               int n_owned, double lam, double mu, int tid, double &sink) {
-  const double2 *r0 = reinterpret_cast<const double2 *>(rec + 6 * c.x);
-  const double2 *r1 = reinterpret_cast<const double2 *>(rec + 6 * c.y);
-  const double2 *r2 = reinterpret_cast<const double2 *>(rec + 6 * c.z);
-  const double2 *r3 = reinterpret_cast<const double2 *>(rec + 6 * c.w);
-  if (ABLATE == 2) {  // every lane reads its own fixed records: no index-dependent LDS traffic
-    r0 = reinterpret_cast<const double2 *>(rec + 6 * (tid & 63)); r1 = r0 + 3; r2 = r0 + 6; r3 = r0 + 9;
+// One work item (saa_plan.h): two face-adjacent tets A = (a; p,q,r) and B = (b; p,r,q) - or a single tet
+// when the flag is 0.  Five node records (three ds_read_b128 each) instead of eight, and the forces of the
+// shared face p,q,r are summed in registers before ONE ds_add_f64 per owned node and component.
+// Both tets are evaluated from p (even re-orderings (p; a,r,q) and (p; b,q,r)), so the face edges are shared.
+struct Item {
+  unsigned a, p, q, r, b;
+  bool pair;
+};
+__device__ __forceinline__ Item unpack(const uint4 w) {
+  return {w.x & 0xffffu, w.x >> 16, w.y & 0xffffu, w.y >> 16, w.z & 0xffffu, (w.z >> 16) != 0u};
+}
+struct Rec {
+  Vec3 x, u;
+};
+__device__ __forceinline__ Rec load_rec(const double *rec, unsigned n) {
+  const double2 *r = reinterpret_cast<const double2 *>(rec + 6 * n);
+  const double2 a = r[0], b = r[1], c = r[2];
+  return {{a.x, a.y, b.x}, {b.y, c.x, c.y}};
+}
+__device__ __forceinline__ void flush(double *acc, int fstride, unsigned n, int n_owned, const Vec3 &f) {
+  if ((int)n < n_owned) {
+    lds_add(acc + n, f.x);
+    lds_add(acc + n + fstride, f.y);
+    lds_add(acc + n + 2 * fstride, f.z);
   }
-  Vec3 f1, f2, f3;
-  if (ABLATE == 6) {  // VALU only: operands from registers, result to a register sink
+}
+__device__ __forceinline__ Vec3 add3(const Vec3 &a, const Vec3 &b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ Vec3 neg_sum3(const Vec3 &a, const Vec3 &b, const Vec3 &c) {
+  return {-(a.x + b.x + c.x), -(a.y + b.y + c.y), -(a.z + b.z + c.z)};
+}
+
+template <int ABLATE>
+__device__ __forceinline__ void item_forces(const uint4 w, const double *rec, double *acc, int fstride, int n_owned,
+                                            double lam, double mu, int tid, double &sink) {
+  Item it = unpack(w);
+  if (ABLATE == 2) {  // every lane reads its own fixed records: no index-dependent LDS traffic
+    it.a = tid & 63; it.p = it.a + 1; it.q = it.a + 2; it.r = it.a + 3; it.b = it.a + 4;
+  }
+  Vec3 fa, fp, fq, fr, fb = {0, 0, 0};
+  if (ABLATE == 6) {  // VALU only: operands from registers, results to a register sink
     const double t = 1.0 + 1e-3 * tid + sink;
+    Vec3 g1, g2, g3;
     tet_forces({t, 0.1, 0.2}, {1.1 * t, 0.3, 0.1}, {0.2, t, 0.3}, {0.1, 0.2, 1.3 * t}, {t, t, 0}, {0, t, t}, {t, 0, t},
-               {t, t, t}, lam, mu, f1, f2, f3);
-    sink += f1.x + f1.y + f1.z + f2.x + f2.y + f2.z + f3.x + f3.y + f3.z;
+               {t, t, t}, lam, mu, fa, fr, fq);
+    tet_forces({t, 0.1, 0.2}, {1.2 * t, 0.3, 0.1}, {0.1, 0.2, 1.3 * t}, {0.2, t, 0.3}, {t, t, 0}, {0, 2 * t, t}, {t, t, t},
+               {t, 0, t}, lam, mu, g1, g2, g3);
+    sink += fa.x + fa.y + fa.z + fr.x + fr.y + fr.z + fq.x + fq.y + fq.z + g1.x + g1.y + g1.z + g2.x + g2.y + g2.z +
+            g3.x + g3.y + g3.z;
     return;
   }
-  const double2 a0 = r0[0], b0 = r0[1], c0 = r0[2], a1 = r1[0], b1 = r1[1], c1 = r1[2];
-  const double2 a2 = r2[0], b2 = r2[1], c2 = r2[2], a3 = r3[0], b3 = r3[1], c3 = r3[2];
-  if (ABLATE == 7) {  // LDS only: reads and atomics without the element arithmetic
-    f1 = {a0.x + a1.y, a0.y + a2.x, b0.x + a3.x};
-    f2 = {b1.x + b0.y, a2.y + c0.x, b2.x + c0.y};
-    f3 = {a3.y + b1.y + c1.x + c1.y, b3.x + b2.y + c2.x + c2.y, b3.y + c3.x + c3.y};
-  } else {
-    tet_forces({a0.x, a0.y, b0.x}, {a1.x, a1.y, b1.x}, {a2.x, a2.y, b2.x}, {a3.x, a3.y, b3.x},
-               {b0.y, c0.x, c0.y}, {b1.y, c1.x, c1.y}, {b2.y, c2.x, c2.y}, {b3.y, c3.x, c3.y}, lam, mu, f1, f2, f3);
+  const Rec rp = load_rec(rec, it.p), rq = load_rec(rec, it.q), rr = load_rec(rec, it.r);
+  {
+    const Rec ra = load_rec(rec, it.a);
+    if (ABLATE == 7) {  // LDS only: reads and atomics without the element arithmetic
+      fa = add3(ra.x, ra.u); fp = add3(rp.x, rp.u); fq = add3(rq.x, rq.u); fr = add3(rr.x, rr.u);
+    } else {
+      // A as (p; a, r, q): forces on a, r, q; p gets minus their sum
+      tet_forces(rp.x, ra.x, rr.x, rq.x, rp.u, ra.u, rr.u, rq.u, lam, mu, fa, fr, fq);
+      fp = neg_sum3(fa, fr, fq);
+    }
+  }
+  if (ABLATE != 1) flush(acc, fstride, it.a, n_owned, fa);
+  else sink += fa.x + fa.y + fa.z;
+  if (it.pair) {
+    const Rec rb = load_rec(rec, it.b);
+    if (ABLATE == 7) {
+      fb = add3(rb.x, rb.u);
+    } else {
+      // B as (p; b, q, r)
+      Vec3 gq, gr;
+      tet_forces(rp.x, rb.x, rq.x, rr.x, rp.u, rb.u, rq.u, rr.u, lam, mu, fb, gq, gr);
+      fp = add3(fp, neg_sum3(fb, gq, gr));
+      fq = add3(fq, gq);
+      fr = add3(fr, gr);
+    }
+    if (ABLATE != 1) flush(acc, fstride, it.b, n_owned, fb);
+    else sink += fb.x + fb.y + fb.z;
   }
   if (ABLATE == 1) {
-    sink += f1.x + f1.y + f1.z + f2.x + f2.y + f2.z + f3.x + f3.y + f3.z;
+    sink += fp.x + fp.y + fp.z + fq.x + fq.y + fq.z + fr.x + fr.y + fr.z;
     return;
   }
-  if (c.x < n_owned) {
-    lds_add(acc + c.x, -(f1.x + f2.x + f3.x));
-    lds_add(acc + c.x + fstride, -(f1.y + f2.y + f3.y));
-    lds_add(acc + c.x + 2 * fstride, -(f1.z + f2.z + f3.z));
-  }
-  if (c.y < n_owned) {
-    lds_add(acc + c.y, f1.x);
-    lds_add(acc + c.y + fstride, f1.y);
-    lds_add(acc + c.y + 2 * fstride, f1.z);
-  }
-  if (c.z < n_owned) {
-    lds_add(acc + c.z, f2.x);
-    lds_add(acc + c.z + fstride, f2.y);
-    lds_add(acc + c.z + 2 * fstride, f2.z);
-  }
-  if (c.w < n_owned) {
-    lds_add(acc + c.w, f3.x);
-    lds_add(acc + c.w + fstride, f3.y);
-    lds_add(acc + c.w + 2 * fstride, f3.z);
-  }
+  flush(acc, fstride, it.p, n_owned, fp);
+  flush(acc, fstride, it.q, n_owned, fq);
+  flush(acc, fstride, it.r, n_owned, fr);
 }
 
 // Per-thread prefetch depth (dofs): the update operands of the first kPreOwn*blockDim owned dofs and
 // the records of the first kPreHalo*blockDim halo dofs travel in registers while elements are computed.
-constexpr int kPreOwn = 3;
-constexpr int kPreHalo = 2;
+#ifndef SAA_KPRE_OWN
+#define SAA_KPRE_OWN 2
+#define SAA_KPRE_HALO 2
+#define SAA_KPRE_CONN 2
+#endif
+constexpr int kPreOwn = SAA_KPRE_OWN;
+constexpr int kPreHalo = SAA_KPRE_HALO;
 // Connectivity of the first kPreConn interior sweeps is fetched BEFORE those loads: vector-memory
 // results return in issue order, so a connectivity load issued later would make the first interior
 // element wait for every prefetch in front of it.
-constexpr int kPreConn = 4;
+constexpr int kPreConn = SAA_KPRE_CONN;
 
 // ABLATE (diagnostic builds only, never launched by the product path): 1 = no LDS atomics,
 // 2 = no indexed LDS reads, 3 = no staging loads, 4 = no update phase, 5 = no element phase.
 template <bool FORCE_ONLY, int ABLATE = 0>
-__global__ void fused_step_kernel(DeviceMesh m, const double *__restrict__ d0, const double *__restrict__ dn,
+__global__ void __launch_bounds__(SAA_LB) fused_step_kernel(DeviceMesh m, const double *__restrict__ d0, const double *__restrict__ dn,
                                   double *__restrict__ out, double *__restrict__ iface, StepConsts k) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const BlockDesc bd = m.blocks[plan_block(blockIdx.x, m.n_blocks)];
@@ -193,8 +233,8 @@ __global__ void fused_step_kernel(DeviceMesh m, const double *__restrict__ d0, c
   const int32_t *hid = m.halo_ids + bd.halo_off;
 
   // ---- 0. interior connectivity and halo ids first (see kPreConn) ------------------------------
-  const ushort4 *conn = m.conn + bd.elem_off;
-  ushort4 cpre[kPreConn];
+  const uint4 *conn = m.conn + bd.elem_off;
+  uint4 cpre[kPreConn];
 #pragma unroll
   // All prefetch loads are UNCONDITIONAL with clamped (always valid) indices: loads under a
   // divergent branch make hipcc fall back to s_waitcnt vmcnt(0) at the first use (the plan pads
@@ -247,22 +287,22 @@ __global__ void fused_step_kernel(DeviceMesh m, const double *__restrict__ d0, c
 #pragma unroll
     for (int j = 0; j < kPreConn; ++j)
       if (tid + j * nt < bd.n_interior)
-        element_forces<ABLATE>(cpre[j], rec, acc, fstride, bd.n_owned, m.lambda_, m.mu, tid, sink);
+        item_forces<ABLATE>(cpre[j], rec, acc, fstride, bd.n_owned, m.lambda_, m.mu, tid, sink);
     // (rare) further interior sweeps, software-pipelined: the next connectivity entry is in flight while
     // the current element computes - a dependent global load per sweep would expose its L2 latency
     if (tid + kPreConn * nt < bd.n_interior) {
       const int last = bd.n_elem - 1;
-      ushort4 cur = conn[tid + kPreConn * nt];
+      uint4 cur = conn[tid + kPreConn * nt];
       for (int e = tid + kPreConn * nt; e < bd.n_interior; e += nt) {
-        const ushort4 nxt = conn[min(e + nt, last)];
-        element_forces<ABLATE>(cur, rec, acc, fstride, bd.n_owned, m.lambda_, m.mu, tid, sink);
+        const uint4 nxt = conn[min(e + nt, last)];
+        item_forces<ABLATE>(cur, rec, acc, fstride, bd.n_owned, m.lambda_, m.mu, tid, sink);
         cur = nxt;
       }
     }
   }
   // first boundary sweep's connectivity: issued now, consumed after the halo records are in LDS
   const int e_b0 = bd.n_interior + tid;
-  ushort4 bcur = conn[min(e_b0, max(bd.n_elem - 1, 0))];
+  uint4 bcur = conn[min(e_b0, max(bd.n_elem - 1, 0))];
 
   // ---- 4. halo records -> LDS --------------------------------------------------------------------
 #pragma unroll
@@ -286,8 +326,8 @@ __global__ void fused_step_kernel(DeviceMesh m, const double *__restrict__ d0, c
   if (ABLATE != 5) {
     const int last = bd.n_elem - 1;
     for (int e = e_b0; e < bd.n_elem; e += nt) {
-      const ushort4 nxt = conn[min(e + nt, last)];
-      element_forces<ABLATE>(bcur, rec, acc, fstride, bd.n_owned, m.lambda_, m.mu, tid, sink);
+      const uint4 nxt = conn[min(e + nt, last)];
+      item_forces<ABLATE>(bcur, rec, acc, fstride, bd.n_owned, m.lambda_, m.mu, tid, sink);
       bcur = nxt;
     }
   }

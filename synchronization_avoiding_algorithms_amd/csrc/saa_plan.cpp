@@ -3,15 +3,18 @@
 
 #include <algorithm>
 #include <atomic>
-#include <thread>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
-#include <cmath>
 #include <numeric>
+#include <thread>
 
 namespace saa {
 namespace {
 
+// ------------------------------------------------------------------------------------------------
+// node blocks: recursive coordinate bisection of the node cloud
+// ------------------------------------------------------------------------------------------------
 struct Rcb {
   const double *xyz;
   std::vector<int32_t> &order;          // node ids being permuted in place
@@ -49,135 +52,6 @@ struct Rcb {
   }
 };
 
-// Re-order (and re-orient) the element copies of one block for the LDS traffic of the element phase
-// (LDS image and bank rules: saa_plan.h).  Measured on gfx950 (tools/lds_microbench.hip): ds_add_f64 costs
-// 7 cycles per wave-instruction conflict-free, 22 for random nodes, 60 when 6 lanes hit one address (the
-// natural order of the 6 tets around a cube diagonal); ds_read_b128 6 conflict-free, 11 random.
-// Packing, one half-wave (32 element slots) at a time: scan the not yet placed elements and take those for
-// which one of the 12 EVEN vertex permutations (orientation, hence signed detJ, is preserved; the nodal
-// forces follow their vertices) and one of the half's two ds_read_b128 lane groups leaves every vertex on
-// a free bank: node mod 16 free in the group (reads), node mod 32 free in the half for owned vertices
-// (atomics).  When the scan window runs dry the placement that raises the worst multiplicities least is
-// taken.  mult_sum / mult_cnt accumulate the worst read multiplicity over (lane group, vertex slot).
-constexpr int kEvenPerms[12][4] = {{0, 1, 2, 3}, {0, 2, 3, 1}, {0, 3, 1, 2}, {1, 0, 3, 2}, {1, 2, 0, 3}, {1, 3, 2, 0},
-                                   {2, 0, 1, 3}, {2, 1, 3, 0}, {2, 3, 0, 1}, {3, 0, 2, 1}, {3, 1, 0, 2}, {3, 2, 1, 0}};
-// ds_read_b128 lane groups of a 32-lane half (MI355X_MICROARCH.md, LDS): {0-3,12-15,20-27} and {4-11,16-19,28-31}
-constexpr int kGroupLanes[2][16] = {{0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27},
-                                    {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31}};
-
-struct PackStats {
-  double read_mult = 0.0, atomic_mult = 0.0;  // sums of worst multiplicities
-  int64_t read_cnt = 0, atomic_cnt = 0;
-};
-
-void reorder_for_lds(std::vector<uint16_t> &conn, int64_t off, int32_t n_elem, int32_t n_owned,
-                     std::vector<uint16_t> &scratch, PackStats &st) {
-  constexpr int kHalf = 32;
-  constexpr int kWindow = 768;  // pool elements examined per half before clashes are accepted
-  if (n_elem <= 0) return;
-  const int32_t n_halves = (n_elem + kHalf - 1) / kHalf;
-  std::vector<int32_t> pool(n_elem);
-  for (int32_t e = 0; e < n_elem; ++e) pool[e] = e;
-  scratch.assign(4 * static_cast<size_t>(n_elem), 0);
-  const uint16_t *src = &conn[4 * static_cast<size_t>(off)];
-  int32_t done = 0;
-  for (int32_t h = 0; h < n_halves; ++h) {
-    const int32_t cap = std::min<int32_t>(kHalf, n_elem - done);
-    // lanes available in this half: lane l exists if l < cap
-    int32_t free_lane[2][16], n_free[2] = {0, 0};
-    for (int g = 0; g < 2; ++g)
-      for (int j = 0; j < 16; ++j)
-        if (kGroupLanes[g][j] < cap) free_lane[g][n_free[g]++] = kGroupLanes[g][j];
-    int used[2] = {0, 0};
-    uint8_t cnt_rd[2][4][16] = {}, cnt_at[4][32] = {};
-    int max_rd[2][4] = {}, max_at[4] = {};
-    uint32_t taken_rd[2][4] = {}, taken_at[4] = {};
-    int32_t placed = 0;
-    auto put = [&](int32_t pool_pos, int perm, int g) {
-      const uint16_t *c = src + 4 * static_cast<size_t>(pool[pool_pos]);
-      const int32_t lane = free_lane[g][used[g]++];
-      for (int a = 0; a < 4; ++a) {
-        const uint16_t v = c[kEvenPerms[perm][a]];
-        scratch[4 * static_cast<size_t>(done + lane) + a] = v;
-        taken_rd[g][a] |= 1u << (v & 15);
-        max_rd[g][a] = std::max<int>(max_rd[g][a], ++cnt_rd[g][a][v & 15]);
-        if (v < n_owned) {
-          taken_at[a] |= 1u << (v & 31);
-          max_at[a] = std::max<int>(max_at[a], ++cnt_at[a][v & 31]);
-        }
-      }
-      ++placed;
-      pool[pool_pos] = -1;
-    };
-    const int32_t lim = std::min<int32_t>(static_cast<int32_t>(pool.size()), kWindow);
-    // pass 1: clash-free placements
-    for (int32_t p = 0; p < lim && placed < cap; ++p) {
-      const uint16_t *c = src + 4 * static_cast<size_t>(pool[p]);
-      bool ok = false;
-      for (int q = 0; q < 12 && !ok; ++q) {
-        const int *pm = kEvenPerms[q];
-        uint32_t at = 0;
-        for (int a = 0; a < 4; ++a)
-          if (c[pm[a]] < n_owned) at |= taken_at[a] >> (c[pm[a]] & 31);
-        if (at & 1u) continue;
-        for (int g = 0; g < 2 && !ok; ++g) {
-          if (used[g] >= n_free[g]) continue;
-          if (((taken_rd[g][0] >> (c[pm[0]] & 15)) | (taken_rd[g][1] >> (c[pm[1]] & 15)) |
-               (taken_rd[g][2] >> (c[pm[2]] & 15)) | (taken_rd[g][3] >> (c[pm[3]] & 15))) & 1u)
-            continue;
-          put(p, q, g);
-          ok = true;
-        }
-      }
-    }
-    // pass 2: fill the rest where it raises the worst multiplicities least (an LDS instruction costs its
-    // WORST bank multiplicity; reads 3 x ds_read_b128 per vertex ~4 cycles a level, atomics 3 x ds_add_f64 ~7)
-    while (placed < cap) {
-      int32_t best_p = -1, best_q = 0, best_g = 0, best_k = 1 << 30;
-      for (int32_t p = 0; p < lim && best_k > 0; ++p) {
-        if (pool[p] < 0) continue;
-        const uint16_t *c = src + 4 * static_cast<size_t>(pool[p]);
-        for (int q = 0; q < 12 && best_k > 0; ++q) {
-          int k_at = 0;
-          for (int a = 0; a < 4; ++a) {
-            const uint16_t v = c[kEvenPerms[q][a]];
-            if (v < n_owned && cnt_at[a][v & 31] + 1 > max_at[a]) k_at += 21;
-          }
-          for (int g = 0; g < 2; ++g) {
-            if (used[g] >= n_free[g]) continue;
-            int k = k_at;
-            for (int a = 0; a < 4; ++a) {
-              const uint16_t v = c[kEvenPerms[q][a]];
-              if (cnt_rd[g][a][v & 15] + 1 > max_rd[g][a]) k += 12;
-            }
-            if (k < best_k) {
-              best_k = k;
-              best_p = p;
-              best_q = q;
-              best_g = g;
-            }
-          }
-        }
-      }
-      put(best_p, best_q, best_g);
-    }
-    pool.erase(std::remove(pool.begin(), pool.begin() + lim, -1), pool.begin() + lim);
-    for (int a = 0; a < 4; ++a) {
-      for (int g = 0; g < 2; ++g)
-        if (n_free[g] > 0) {
-          st.read_mult += max_rd[g][a];
-          ++st.read_cnt;
-        }
-      if (max_at[a] > 0) {
-        st.atomic_mult += max_at[a];
-        ++st.atomic_cnt;
-      }
-    }
-    done += cap;
-  }
-  std::copy(scratch.begin(), scratch.end(), conn.begin() + 4 * off);
-}
-
 int32_t choose_block_count(int32_t n_nodes, int32_t block_nodes) {
   int64_t nb = (static_cast<int64_t>(n_nodes) + block_nodes - 1) / block_nodes;
   // MI355X has 256 CUs: once there is more than about a chip-full of blocks, make the count a
@@ -199,6 +73,254 @@ int32_t auto_block_nodes(int32_t n_nodes) {
   return kDefaultBlockNodes;
 }
 
+// ------------------------------------------------------------------------------------------------
+// work items: pairs of face-adjacent elements
+// ------------------------------------------------------------------------------------------------
+// The 12 even permutations of 4 vertices: re-ordering a tet by one of them keeps its orientation (the
+// sign of detJ the reference keeps, Mat_construction.py:93) and therefore its nodal forces.
+constexpr int kEvenPerms[12][4] = {{0, 1, 2, 3}, {0, 2, 3, 1}, {0, 3, 1, 2}, {1, 0, 3, 2}, {1, 2, 0, 3}, {1, 3, 2, 0},
+                                   {2, 0, 1, 3}, {2, 1, 3, 0}, {2, 3, 0, 1}, {3, 0, 2, 1}, {3, 1, 0, 2}, {3, 2, 1, 0}};
+
+// Item vertex order (a, p, q, r, b): tets A = (a; p,q,r) and B = (b; p,r,q).  Relabellings that keep
+// both orientations: rotations of (p,q,r) and the exchange A<->B (a<->b together with q<->r).
+constexpr int kPairSyms[6][5] = {{0, 1, 2, 3, 4}, {0, 2, 3, 1, 4}, {0, 3, 1, 2, 4},
+                                 {4, 1, 3, 2, 0}, {4, 3, 2, 1, 0}, {4, 2, 1, 3, 0}};
+
+// Greedy matching of the block's elements into face-sharing pairs with compatible orientation.
+// in: loc = 4 block-local node ids per element.  out: items (8 uint16 each); returns their number.
+int32_t build_items(const std::vector<uint16_t> &loc, int32_t n_elem, std::vector<uint16_t> &items) {
+  struct Face {
+    uint64_t key;
+    int32_t elem;
+    int32_t omit;
+  };
+  std::vector<Face> faces(4 * static_cast<size_t>(n_elem));
+  for (int32_t e = 0; e < n_elem; ++e)
+    for (int k = 0; k < 4; ++k) {
+      uint16_t t[3];
+      int m = 0;
+      for (int a = 0; a < 4; ++a)
+        if (a != k) t[m++] = loc[4 * static_cast<size_t>(e) + a];
+      std::sort(t, t + 3);
+      faces[4 * static_cast<size_t>(e) + k] = {
+          (static_cast<uint64_t>(t[0]) << 32) | (static_cast<uint64_t>(t[1]) << 16) | t[2], e, k};
+    }
+  std::sort(faces.begin(), faces.end(),
+            [](const Face &x, const Face &y) { return x.key < y.key || (x.key == y.key && x.elem < y.elem); });
+  // nb[e][k] = element across the face opposite vertex k, nbk = the vertex IT omits; -1: none in this block
+  std::vector<int32_t> nb(4 * static_cast<size_t>(n_elem), -1), nbk(4 * static_cast<size_t>(n_elem), 0);
+  for (size_t i = 0; i + 1 < faces.size(); ++i) {
+    if (faces[i].key != faces[i + 1].key) continue;
+    if (i + 2 < faces.size() && faces[i + 2].key == faces[i].key) continue;  // non-manifold face: leave alone
+    if (i > 0 && faces[i - 1].key == faces[i].key) continue;
+    nb[4 * static_cast<size_t>(faces[i].elem) + faces[i].omit] = faces[i + 1].elem;
+    nbk[4 * static_cast<size_t>(faces[i].elem) + faces[i].omit] = faces[i + 1].omit;
+    nb[4 * static_cast<size_t>(faces[i + 1].elem) + faces[i + 1].omit] = faces[i].elem;
+    nbk[4 * static_cast<size_t>(faces[i + 1].elem) + faces[i + 1].omit] = faces[i].omit;
+  }
+  auto apex_first = [&](int32_t e, int k, uint16_t out[4]) {  // even permutation with vertex k in front
+    for (const auto &pm : kEvenPerms)
+      if (pm[0] == k) {
+        for (int a = 0; a < 4; ++a) out[a] = loc[4 * static_cast<size_t>(e) + pm[a]];
+        return;
+      }
+  };
+  // B = (b; x,y,z) pairs with A = (a; p,q,r) iff (x,y,z) is a rotation of (p,r,q)
+  auto compatible = [](const uint16_t A[4], const uint16_t B[4]) {
+    for (int t = 0; t < 3; ++t)
+      if (B[1 + t] == A[1] && B[1 + (t + 1) % 3] == A[3] && B[1 + (t + 2) % 3] == A[2]) return true;
+    return false;
+  };
+  std::vector<char> used(n_elem, 0);
+  auto free_degree = [&](int32_t e) {
+    int d = 0;
+    for (int k = 0; k < 4; ++k) {
+      const int32_t f = nb[4 * static_cast<size_t>(e) + k];
+      d += (f >= 0 && !used[f]);
+    }
+    return d;
+  };
+  items.clear();
+  items.reserve(8 * static_cast<size_t>(n_elem));
+  int32_t n_items = 0;
+  for (int32_t e = 0; e < n_elem; ++e) {
+    if (used[e]) continue;
+    used[e] = 1;
+    int best_k = -1, best_deg = 99;
+    uint16_t A[4], B[4];
+    for (int k = 0; k < 4; ++k) {
+      const int32_t f = nb[4 * static_cast<size_t>(e) + k];
+      if (f < 0 || used[f]) continue;
+      apex_first(e, k, A);
+      apex_first(f, nbk[4 * static_cast<size_t>(e) + k], B);
+      if (!compatible(A, B)) continue;
+      const int d = free_degree(f);  // take the neighbour that has the fewest other options left
+      if (d < best_deg) {
+        best_deg = d;
+        best_k = k;
+      }
+    }
+    uint16_t it[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (best_k >= 0) {
+      const int32_t f = nb[4 * static_cast<size_t>(e) + best_k];
+      used[f] = 1;
+      apex_first(e, best_k, A);
+      apex_first(f, nbk[4 * static_cast<size_t>(e) + best_k], B);
+      it[0] = A[0], it[1] = A[1], it[2] = A[2], it[3] = A[3], it[4] = B[0], it[5] = 1;
+    } else {
+      for (int a = 0; a < 4; ++a) it[a] = loc[4 * static_cast<size_t>(e) + a];
+      it[4] = it[1];  // dummy second apex: a valid LDS index that is read but never accumulated
+      it[5] = 0;
+    }
+    items.insert(items.end(), it, it + 8);
+    ++n_items;
+  }
+  return n_items;
+}
+
+// ------------------------------------------------------------------------------------------------
+// LDS packing of the items of one block part
+// ------------------------------------------------------------------------------------------------
+// ds_read_b128 lane groups of a 32-lane half (MI355X_MICROARCH.md, LDS): {0-3,12-15,20-27}, {4-11,16-19,28-31}
+constexpr int kGroupLanes[2][16] = {{0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27},
+                                    {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31}};
+
+struct PackStats {
+  double read_mult = 0.0, atomic_mult = 0.0;  // sums of worst multiplicities
+  int64_t read_cnt = 0, atomic_cnt = 0;
+};
+
+// Re-order (and re-label) the items of one block part for the LDS traffic of the element phase (LDS image
+// and bank rules: saa_plan.h).  Measured on gfx950 (tools/lds_microbench.hip): ds_add_f64 costs 7 cycles per
+// wave-instruction conflict-free, 22 for random nodes, 60 when 6 lanes hit one address (the natural order
+// of the 6 tets around a cube diagonal); ds_read_b128 6 conflict-free, 11 random.
+// Packing, one half-wave (32 item slots) at a time: scan the not yet placed items and take those for which
+// one orientation-preserving relabelling (6 for a pair, 12 for a single tet) and one of the half's two
+// ds_read_b128 lane groups leaves every vertex on a free bank: node mod 16 free in the group (reads), node
+// mod 32 free in the half for owned vertices (atomics).  When the scan window runs dry the placement that
+// raises the worst multiplicities least is taken.
+void reorder_for_lds(uint16_t *items, int32_t n_items, int32_t n_owned, std::vector<uint16_t> &scratch,
+                     PackStats &st) {
+  constexpr int kHalf = 32, kSlots = 5;
+  constexpr int kWindow = 768;  // pool items examined per half before clashes are accepted
+  if (n_items <= 0) return;
+  const int32_t n_halves = (n_items + kHalf - 1) / kHalf;
+  std::vector<int32_t> pool(n_items);
+  for (int32_t e = 0; e < n_items; ++e) pool[e] = e;
+  scratch.assign(8 * static_cast<size_t>(n_items), 0);
+  auto n_syms = [](const uint16_t *it) { return it[5] ? 6 : 12; };
+  auto relabel = [](const uint16_t *it, int q, uint16_t out[5]) {
+    if (it[5]) {
+      for (int a = 0; a < kSlots; ++a) out[a] = it[kPairSyms[q][a]];
+    } else {
+      for (int a = 0; a < 4; ++a) out[a] = it[kEvenPerms[q][a]];
+      out[4] = out[1];  // dummy: p's record again (same address = broadcast), never accumulated
+    }
+  };
+  int32_t done = 0;
+  for (int32_t h = 0; h < n_halves; ++h) {
+    const int32_t cap = std::min<int32_t>(kHalf, n_items - done);
+    int32_t free_lane[2][16], n_free[2] = {0, 0};
+    for (int g = 0; g < 2; ++g)
+      for (int j = 0; j < 16; ++j)
+        if (kGroupLanes[g][j] < cap) free_lane[g][n_free[g]++] = kGroupLanes[g][j];
+    int used[2] = {0, 0};
+    uint8_t cnt_rd[2][kSlots][16] = {}, cnt_at[kSlots][32] = {};
+    int max_rd[2][kSlots] = {}, max_at[kSlots] = {};
+    uint32_t taken_rd[2][kSlots] = {}, taken_at[kSlots] = {};
+    int32_t placed = 0;
+    auto put = [&](int32_t pool_pos, int q, int g) {
+      const uint16_t *it = items + 8 * static_cast<size_t>(pool[pool_pos]);
+      uint16_t v[5];
+      relabel(it, q, v);
+      const int32_t lane = free_lane[g][used[g]++];
+      uint16_t *dst = &scratch[8 * static_cast<size_t>(done + lane)];
+      const int real = it[5] ? 5 : 4;
+      for (int a = 0; a < kSlots; ++a) {
+        dst[a] = v[a];
+        if (a >= real) continue;
+        taken_rd[g][a] |= 1u << (v[a] & 15);
+        max_rd[g][a] = std::max<int>(max_rd[g][a], ++cnt_rd[g][a][v[a] & 15]);
+        if (v[a] < n_owned) {
+          taken_at[a] |= 1u << (v[a] & 31);
+          max_at[a] = std::max<int>(max_at[a], ++cnt_at[a][v[a] & 31]);
+        }
+      }
+      dst[5] = it[5];
+      ++placed;
+      pool[pool_pos] = -1;
+    };
+    const int32_t lim = std::min<int32_t>(static_cast<int32_t>(pool.size()), kWindow);
+    // pass 1: clash-free placements
+    for (int32_t p = 0; p < lim && placed < cap; ++p) {
+      const uint16_t *it = items + 8 * static_cast<size_t>(pool[p]);
+      const int real = it[5] ? 5 : 4;
+      bool ok = false;
+      for (int q = 0; q < n_syms(it) && !ok; ++q) {
+        uint16_t v[5];
+        relabel(it, q, v);
+        uint32_t at = 0;
+        for (int a = 0; a < real; ++a)
+          if (v[a] < n_owned) at |= taken_at[a] >> (v[a] & 31);
+        if (at & 1u) continue;
+        for (int g = 0; g < 2 && !ok; ++g) {
+          if (used[g] >= n_free[g]) continue;
+          uint32_t rd = 0;
+          for (int a = 0; a < real; ++a) rd |= taken_rd[g][a] >> (v[a] & 15);
+          if (rd & 1u) continue;
+          put(p, q, g);
+          ok = true;
+        }
+      }
+    }
+    // pass 2: fill the rest where it raises the worst multiplicities least (an LDS instruction costs its
+    // WORST bank multiplicity; reads 3 x ds_read_b128 per vertex ~4 cycles a level, atomics 3 x ds_add_f64 ~7)
+    while (placed < cap) {
+      int32_t best_p = -1, best_q = 0, best_g = 0, best_k = 1 << 30;
+      for (int32_t p = 0; p < lim && best_k > 0; ++p) {
+        if (pool[p] < 0) continue;
+        const uint16_t *it = items + 8 * static_cast<size_t>(pool[p]);
+        const int real = it[5] ? 5 : 4;
+        for (int q = 0; q < n_syms(it) && best_k > 0; ++q) {
+          uint16_t v[5];
+          relabel(it, q, v);
+          int k_at = 0;
+          for (int a = 0; a < real; ++a)
+            if (v[a] < n_owned && cnt_at[a][v[a] & 31] + 1 > max_at[a]) k_at += 21;
+          for (int g = 0; g < 2; ++g) {
+            if (used[g] >= n_free[g]) continue;
+            int k = k_at;
+            for (int a = 0; a < real; ++a)
+              if (cnt_rd[g][a][v[a] & 15] + 1 > max_rd[g][a]) k += 12;
+            if (k < best_k) {
+              best_k = k;
+              best_p = p;
+              best_q = q;
+              best_g = g;
+            }
+          }
+        }
+      }
+      put(best_p, best_q, best_g);
+    }
+    pool.erase(std::remove(pool.begin(), pool.begin() + lim, -1), pool.begin() + lim);
+    for (int a = 0; a < kSlots; ++a) {
+      for (int g = 0; g < 2; ++g)
+        if (max_rd[g][a] > 0) {
+          st.read_mult += max_rd[g][a];
+          ++st.read_cnt;
+        }
+      if (max_at[a] > 0) {
+        st.atomic_mult += max_at[a];
+        ++st.atomic_cnt;
+      }
+    }
+    done += cap;
+  }
+  std::copy(scratch.begin(), scratch.end(), items);
+}
+
+// ------------------------------------------------------------------------------------------------
 bool build_once(int32_t n_nodes, int32_t n_elems, const double *xyz, const int32_t *tets,
                 int32_t block_nodes, Plan &plan, std::string &err, bool &too_big) {
   too_big = false;
@@ -257,17 +379,14 @@ bool build_once(int32_t n_nodes, int32_t n_elems, const double *xyz, const int32
     }
   }
 
+  // ---- per block (serial, cheap): halo list and block-local connectivity ---------------------------
   plan.blocks.resize(n_blocks);
-  plan.conn.resize(4 * static_cast<size_t>(plan.n_elem_copies));
+  std::vector<uint16_t> loc(4 * static_cast<size_t>(plan.n_elem_copies));
   std::vector<int32_t> tmp;
-  std::vector<uint16_t> reorder_scratch;
-  std::vector<char> interior_flag;
   for (int32_t b = 0; b < n_blocks; ++b) {
     BlockDesc &d = plan.blocks[b];
     d.node_start = block_start[b];
     d.n_owned = block_start[b + 1] - block_start[b];
-    d.elem_off = static_cast<int32_t>(off[b]);
-    d.n_elem = static_cast<int32_t>(off[b + 1] - off[b]);
     d.halo_off = static_cast<int32_t>(plan.halo_ids.size());
     const int32_t lo = d.node_start, hi = d.node_start + d.n_owned;
     tmp.clear();
@@ -286,71 +405,95 @@ bool build_once(int32_t n_nodes, int32_t n_elems, const double *xyz, const int32
     for (int64_t c = off[b]; c < off[b + 1]; ++c)
       for (int a = 0; a < 4; ++a) {
         const int32_t g = plan.old_to_new[tets[4 * static_cast<int64_t>(elem_of[c]) + a]];
-        int32_t loc;
+        int32_t l;
         if (g >= lo && g < hi)
-          loc = g - lo;
+          l = g - lo;
         else
-          loc = d.n_owned + static_cast<int32_t>(std::lower_bound(tmp.begin(), tmp.end(), g) - tmp.begin());
-        plan.conn[4 * static_cast<size_t>(c) + a] = static_cast<uint16_t>(loc);
+          l = d.n_owned + static_cast<int32_t>(std::lower_bound(tmp.begin(), tmp.end(), g) - tmp.begin());
+        loc[4 * static_cast<size_t>(c) + a] = static_cast<uint16_t>(l);
       }
-    // interior elements first (they can run before the halo records have arrived), then each part
-    // gets its own conflict-avoiding order
-    {
-      uint16_t *cb = &plan.conn[4 * static_cast<size_t>(off[b])];
-      reorder_scratch.assign(cb, cb + 4 * static_cast<size_t>(d.n_elem));
-      int32_t lo_i = 0, hi_i = d.n_elem;
-      for (int32_t e = 0; e < d.n_elem; ++e) {
-        const uint16_t *c = &reorder_scratch[4 * static_cast<size_t>(e)];
-        const bool interior = c[0] < d.n_owned && c[1] < d.n_owned && c[2] < d.n_owned && c[3] < d.n_owned;
-        interior_flag.push_back(interior);
-        if (interior) ++lo_i;
-      }
-      d.n_interior = lo_i;
-      int32_t wi = 0, wb = lo_i;
-      for (int32_t e = 0; e < d.n_elem; ++e) {
-        const int32_t dst = interior_flag[e] ? wi++ : wb++;
-        std::copy(&reorder_scratch[4 * static_cast<size_t>(e)], &reorder_scratch[4 * static_cast<size_t>(e)] + 4,
-                  cb + 4 * static_cast<size_t>(dst));
-      }
-      (void)hi_i;
-      interior_flag.clear();
-    }
-    d.pad_ = 0;
     plan.halo_ids.insert(plan.halo_ids.end(), tmp.begin(), tmp.end());
     plan.max_owned = std::max(plan.max_owned, d.n_owned);
     plan.max_local = std::max(plan.max_local, d.n_owned + d.n_halo);
     plan.n_halo_total += d.n_halo;
   }
-  // LDS packing of every block's interior and boundary element lists: independent per block -> threads
-  {
-    const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
-    const unsigned n_thr = static_cast<unsigned>(std::min<int64_t>(hw, std::max<int32_t>(1, n_blocks / 8)));
-    std::vector<PackStats> stats(n_thr);
-    std::atomic<int32_t> next{0};
-    auto work = [&](unsigned t) {
-      std::vector<uint16_t> scratch;
-      for (int32_t b = next.fetch_add(1); b < n_blocks; b = next.fetch_add(1)) {
-        const BlockDesc &d = plan.blocks[b];
-        reorder_for_lds(plan.conn, off[b], d.n_interior, d.n_owned, scratch, stats[t]);
-        reorder_for_lds(plan.conn, off[b] + d.n_interior, d.n_elem - d.n_interior, d.n_owned, scratch, stats[t]);
+
+  // ---- per block (threads): pair the elements, split interior / boundary items, pack for the LDS ----
+  std::vector<std::vector<uint16_t>> block_items(n_blocks);
+  std::vector<int32_t> n_interior(n_blocks, 0), n_items(n_blocks, 0), n_paired(n_blocks, 0);
+  const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+  const unsigned n_thr = static_cast<unsigned>(std::min<int64_t>(hw, std::max<int32_t>(1, n_blocks / 8)));
+  std::vector<PackStats> stats(n_thr);
+  std::atomic<int32_t> next{0};
+  auto work = [&](unsigned t) {
+    std::vector<uint16_t> items, scratch, loc_b;
+    std::vector<char> interior;
+    for (int32_t b = next.fetch_add(1); b < n_blocks; b = next.fetch_add(1)) {
+      const BlockDesc &d = plan.blocks[b];
+      const int32_t ne = static_cast<int32_t>(off[b + 1] - off[b]);
+      loc_b.assign(loc.begin() + 4 * off[b], loc.begin() + 4 * off[b + 1]);
+      const int32_t ni = build_items(loc_b, ne, items);
+      // interior items (every real vertex owned) first: they can run before the halo records arrive
+      std::vector<uint16_t> &out = block_items[b];
+      out.resize(8 * static_cast<size_t>(ni));
+      int32_t n_in = 0, paired = 0;
+      interior.assign(ni, 0);
+      for (int32_t i = 0; i < ni; ++i) {
+        const uint16_t *it = &items[8 * static_cast<size_t>(i)];
+        bool in = true;
+        for (int a = 0; a < (it[5] ? 5 : 4); ++a) in &= it[a] < d.n_owned;
+        interior[i] = in;
+        n_in += in;
+        paired += it[5];
       }
-    };
+      int32_t wi = 0, wb = n_in;
+      for (int32_t i = 0; i < ni; ++i) {
+        const int32_t dst = interior[i] ? wi++ : wb++;
+        std::copy(&items[8 * static_cast<size_t>(i)], &items[8 * static_cast<size_t>(i)] + 8,
+                  &out[8 * static_cast<size_t>(dst)]);
+      }
+      reorder_for_lds(out.data(), n_in, d.n_owned, scratch, stats[t]);
+      reorder_for_lds(out.data() + 8 * static_cast<size_t>(n_in), ni - n_in, d.n_owned, scratch, stats[t]);
+      n_interior[b] = n_in;
+      n_items[b] = ni;
+      n_paired[b] = paired;
+    }
+  };
+  {
     std::vector<std::thread> pool;
     for (unsigned t = 1; t < n_thr; ++t) pool.emplace_back(work, t);
     work(0);
     for (auto &th : pool) th.join();
-    PackStats tot;
-    for (const auto &st : stats) {
-      tot.read_mult += st.read_mult;
-      tot.read_cnt += st.read_cnt;
-      tot.atomic_mult += st.atomic_mult;
-      tot.atomic_cnt += st.atomic_cnt;
-    }
-    plan.lds_conflict_factor = tot.read_cnt ? tot.read_mult / tot.read_cnt : 1.0;
-    if (getenv("SAA_PLAN_DEBUG"))
-      fprintf(stderr, "plan: read conflict factor %.3f, atomic conflict factor %.3f (%u threads)\n",
-              plan.lds_conflict_factor, tot.atomic_cnt ? tot.atomic_mult / tot.atomic_cnt : 1.0, n_thr);
   }
+  int64_t total_items = 0;
+  for (int32_t b = 0; b < n_blocks; ++b) total_items += n_items[b];
+  plan.conn.resize(8 * static_cast<size_t>(total_items));
+  int64_t pos = 0;
+  for (int32_t b = 0; b < n_blocks; ++b) {
+    BlockDesc &d = plan.blocks[b];
+    d.elem_off = static_cast<int32_t>(pos);
+    d.n_elem = n_items[b];
+    d.n_interior = n_interior[b];
+    d.pad_ = 0;
+    std::copy(block_items[b].begin(), block_items[b].end(), plan.conn.begin() + 8 * pos);
+    pos += n_items[b];
+    plan.n_pairs += n_paired[b];
+  }
+  plan.n_items = total_items;
+  PackStats tot;
+  for (const auto &st : stats) {
+    tot.read_mult += st.read_mult;
+    tot.read_cnt += st.read_cnt;
+    tot.atomic_mult += st.atomic_mult;
+    tot.atomic_cnt += st.atomic_cnt;
+  }
+  plan.lds_conflict_factor = tot.read_cnt ? tot.read_mult / tot.read_cnt : 1.0;
+  if (getenv("SAA_PLAN_DEBUG"))
+    fprintf(stderr,
+            "plan: %lld element copies in %lld items (%lld pairs); read conflict factor %.3f, atomic %.3f (%u threads)\n",
+            static_cast<long long>(plan.n_elem_copies), static_cast<long long>(plan.n_items),
+            static_cast<long long>(plan.n_pairs), plan.lds_conflict_factor,
+            tot.atomic_cnt ? tot.atomic_mult / tot.atomic_cnt : 1.0, n_thr);
   return true;
 }
 

@@ -18,9 +18,9 @@ struct BlockDesc {
   int32_t n_owned;
   int32_t halo_off;    // offset into halo_ids
   int32_t n_halo;
-  int32_t elem_off;    // offset into conn (element copies)
-  int32_t n_elem;
-  int32_t n_interior;  // elements [0,n_interior) touch owned nodes only; the rest need halo records
+  int32_t elem_off;    // offset into conn, in work items
+  int32_t n_elem;      // work items of the block (pairs of face-adjacent elements, or single elements)
+  int32_t n_interior;  // items [0,n_interior) touch owned nodes only; the rest need halo records
   int32_t pad_;
 };
 
@@ -42,7 +42,11 @@ struct Plan {
   std::vector<int32_t> old_to_new;
   std::vector<BlockDesc> blocks;
   std::vector<int32_t> halo_ids;    // internal node ids, per block sorted ascending
-  std::vector<uint16_t> conn;       // 4 block-local node indices per element copy (owned nodes first)
+  // Work items, 8 x uint16 each: block-local node indices (a, p, q, r, b), flag, 0, 0.  flag = 1: the two
+  // face-adjacent tets A = (a; p,q,r) and B = (b; p,r,q) (5 node records and 5 force flushes for two
+  // elements instead of 8 + 8); flag = 0: the single tet (a, p, q, r), b = p as a harmless dummy.
+  std::vector<uint16_t> conn;
+  int64_t n_items = 0, n_pairs = 0;
   double lds_conflict_factor = 1.0; // mean over (half-wave, vertex slot) of the worst bank multiplicity
   int32_t max_owned = 0, max_local = 0;
   int64_t n_elem_copies = 0, n_halo_total = 0;
