@@ -122,10 +122,10 @@ __device__ __forceinline__ void lds_barrier() {
 // Both tets are evaluated from p (even re-orderings (p; a,r,q) and (p; b,q,r)), so the face edges are shared.
 struct Item {
   unsigned a, p, q, r, b;
-  bool pair;
+  bool pair, null;
 };
 __device__ __forceinline__ Item unpack(const uint4 w) {
-  return {w.x & 0xffffu, w.x >> 16, w.y & 0xffffu, w.y >> 16, w.z & 0xffffu, (w.z >> 16) != 0u};
+  return {w.x & 0xffffu, w.x >> 16, w.y & 0xffffu, w.y >> 16, w.z & 0xffffu, (w.z >> 16) == 1u, (w.z >> 16) == 2u};
 }
 struct Rec {
   Vec3 x, u;
@@ -151,6 +151,7 @@ template <int ABLATE>
 __device__ __forceinline__ void item_forces(const uint4 w, const double *rec, double *acc, int fstride, int n_owned,
                                             double lam, double mu, int tid, double &sink) {
   Item it = unpack(w);
+  if (it.null) return;  // idle lane left by the LDS packing (saa_plan.cpp)
   if (ABLATE == 2) {  // every lane reads its own fixed records: no index-dependent LDS traffic
     it.a = tid & 63; it.p = it.a + 1; it.q = it.a + 2; it.r = it.a + 3; it.b = it.a + 4;
   }

@@ -44,7 +44,8 @@ struct Plan {
   std::vector<int32_t> halo_ids;    // internal node ids, per block sorted ascending
   // Work items, 8 x uint16 each: block-local node indices (a, p, q, r, b), flag, 0, 0.  flag = 1: the two
   // face-adjacent tets A = (a; p,q,r) and B = (b; p,r,q) (5 node records and 5 force flushes for two
-  // elements instead of 8 + 8); flag = 0: the single tet (a, p, q, r), b = p as a harmless dummy.
+  // elements instead of 8 + 8); flag = 0: the single tet (a, p, q, r), b = p as a harmless dummy;
+  // flag = 2: null item (an idle lane left by the LDS packing).
   std::vector<uint16_t> conn;
   int64_t n_items = 0, n_pairs = 0;
   double lds_conflict_factor = 1.0; // mean over (half-wave, vertex slot) of the worst bank multiplicity
