@@ -134,6 +134,18 @@ int saa_set_interface_buffer(saa_solver *s, double *iface_dev);
 int saa_step_begin(saa_solver *s);
 int saa_step_finish(saa_solver *s, double *hist_dev, int64_t hist_row);
 
+/* Optional native exchange: the per-step all-reduce issued from C++ on the handle's stream through the
+ * RCCL library that is already loaded in the process (e.g. PyTorch-ROCm's librccl.so, given by path), so that
+ * a synchronised step costs three enqueues and no interpreter time.
+ *   saa_comm_unique_id : rank 0 creates the 128-byte ncclUniqueId; the caller broadcasts it to every rank
+ *   saa_comm_init      : every rank joins (ncclCommInitRank); needs saa_set_interface_buffer first
+ *   saa_step_synced    : nsteps x (saa_step_begin, ncclAllReduce(sum, fp64) of the interface buffer,
+ *                        saa_step_finish); history rows hist_row0 + k as in saa_step_finish
+ * With world == 1 the collective is the identity (used by the single-GPU tests). */
+int saa_comm_unique_id(const char *rccl_path, uint8_t id_out[128]);
+int saa_comm_init(saa_solver *s, const char *rccl_path, const uint8_t id[128], int32_t rank, int32_t world);
+int saa_step_synced(saa_solver *s, int32_t nsteps, double *hist_dev, int64_t hist_row0);
+
 /* nsteps sync-free steps of the predicted phase (Online_predictor.py:287-316): after each local
  * update the shared dofs are overwritten by row (table_row0 + k) of table_dev (row length
  * 3*n_shared, fp64) and recorded into row (hist_row0 + k) of hist_dev (may be NULL). */

@@ -14,7 +14,7 @@ _CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("SAA_LIB_PATH") or os.path.join(_HERE, "libsaa_hip.so")  # override: experiments only
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "saa_hip.h")
 SOURCES = ["saa_plan.cpp", "saa_kernels.hip", "saa_api.cpp"]
-HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics"]
+HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics", "-ldl"]
 
 SAA_OK, SAA_E_ARG, SAA_E_HIP, SAA_E_STATE, SAA_E_CAPACITY = 0, -1, -2, -3, -4
 
@@ -73,6 +73,9 @@ SIGNATURES = {
     "saa_set_interface_buffer": (C.c_int, [_H, C.c_void_p]),
     "saa_step_begin": (C.c_int, [_H]),
     "saa_step_finish": (C.c_int, [_H, C.c_void_p, C.c_int64]),
+    "saa_comm_unique_id": (C.c_int, [C.c_char_p, C.POINTER(C.c_uint8)]),
+    "saa_comm_init": (C.c_int, [_H, C.c_char_p, C.POINTER(C.c_uint8), C.c_int32, C.c_int32]),
+    "saa_step_synced": (C.c_int, [_H, C.c_int32, C.c_void_p, C.c_int64]),
     "saa_step_predicted": (C.c_int, [_H, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]),
     "saa_halo_gather": (C.c_int, [_H, C.c_void_p]),
     "saa_halo_scatter": (C.c_int, [_H, C.c_void_p]),

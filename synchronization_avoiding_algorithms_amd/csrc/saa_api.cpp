@@ -1,6 +1,7 @@
 // C ABI of libsaa_hip.so (see include/saa_hip.h): handle management, host<->device marshalling in the
 // caller's numbering, step sequencing.  All numerics live in saa_kernels.hip.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <cmath>
 #include <cstring>
@@ -29,6 +30,42 @@ int fail(int code, const std::string &msg) {
   } while (0)
 
 constexpr int kLdsBudget = 160 * 1024;
+
+// The few RCCL entry points the native exchange needs, resolved from the library already loaded in the
+// process (nothing is linked: the build has no RCCL dependency).  Types as in rccl.h.
+struct NcclUniqueId {
+  char internal[128];
+};
+struct NcclApi {
+  void *lib = nullptr;
+  int (*GetUniqueId)(NcclUniqueId *) = nullptr;
+  int (*CommInitRank)(void **, int, NcclUniqueId, int) = nullptr;
+  int (*CommDestroy)(void *) = nullptr;
+  int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+  const char *(*GetErrorString)(int) = nullptr;
+};
+constexpr int kNcclDouble = 8, kNcclSum = 0;  // ncclDataType_t / ncclRedOp_t values of rccl.h
+
+bool load_nccl(const char *path, NcclApi &api, std::string &err) {
+  if (api.lib) return true;
+  void *h = dlopen(path && *path ? path : "librccl.so", RTLD_NOW | RTLD_GLOBAL);
+  if (!h) {
+    err = std::string("dlopen(") + (path ? path : "librccl.so") + "): " + dlerror();
+    return false;
+  }
+  api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
+  api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
+  api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+  api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(dlsym(h, "ncclAllReduce"));
+  api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+  if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllReduce || !api.GetErrorString) {
+    err = "RCCL library lacks ncclGetUniqueId/ncclCommInitRank/ncclAllReduce";
+    return false;
+  }
+  api.lib = h;
+  return true;
+}
+NcclApi g_nccl;
 
 template <typename T>
 struct DevBuf {
@@ -75,6 +112,8 @@ struct saa_solver {
   bool pending = false;
   int32_t n_shared = 0, n_global_shared = 0;
   std::vector<double> host_tmp;
+  void *comm = nullptr;  // ncclComm_t of the native exchange (saa_comm_init)
+  int32_t comm_world = 0;
 
   void rotate() {
     const int old_n = in_;
@@ -354,6 +393,7 @@ int saa_destroy(saa_solver *s) {
   if (!s) return SAA_OK;
   (void)hipSetDevice(s->device);
   (void)hipStreamSynchronize(s->stream);
+  if (s->comm && g_nccl.CommDestroy) (void)g_nccl.CommDestroy(s->comm);
   s->release_all();
   delete s;
   return SAA_OK;
@@ -484,6 +524,57 @@ int saa_step_finish(saa_solver *s, double *hist_dev, int64_t hist_row) {
   s->pending = false;
   s->rotate();
   s->tn = s->tn + s->consts.dt;
+  return check_launch();
+}
+
+int saa_comm_unique_id(const char *rccl_path, uint8_t id_out[128]) {
+  if (!id_out) return fail(SAA_E_ARG, "saa_comm_unique_id: null output");
+  std::string err;
+  if (!load_nccl(rccl_path, g_nccl, err)) return fail(SAA_E_HIP, err);
+  NcclUniqueId id;
+  const int rc = g_nccl.GetUniqueId(&id);
+  if (rc != 0) return fail(SAA_E_HIP, std::string("ncclGetUniqueId: ") + g_nccl.GetErrorString(rc));
+  std::memcpy(id_out, id.internal, 128);
+  return SAA_OK;
+}
+
+int saa_comm_init(saa_solver *s, const char *rccl_path, const uint8_t id_in[128], int32_t rank, int32_t world) {
+  if (!s || !id_in || world < 1 || rank < 0 || rank >= world) return fail(SAA_E_ARG, "saa_comm_init: bad argument");
+  if (s->comm) return fail(SAA_E_STATE, "saa_comm_init: communicator already initialised");
+  if (s->n_global_shared > 0 && !s->iface) return fail(SAA_E_STATE, "saa_comm_init: set the interface buffer first");
+  std::string err;
+  if (!load_nccl(rccl_path, g_nccl, err)) return fail(SAA_E_HIP, err);
+  HIP_TRY(hipSetDevice(s->device));
+  NcclUniqueId id;
+  std::memcpy(id.internal, id_in, 128);
+  void *comm = nullptr;
+  const int rc = g_nccl.CommInitRank(&comm, world, id, rank);
+  if (rc != 0) return fail(SAA_E_HIP, std::string("ncclCommInitRank: ") + g_nccl.GetErrorString(rc));
+  s->comm = comm;
+  s->comm_world = world;
+  return SAA_OK;
+}
+
+int saa_step_synced(saa_solver *s, int32_t nsteps, double *hist_dev, int64_t hist_row0) {
+  if (!s || nsteps < 0 || (hist_dev && hist_row0 < 0)) return fail(SAA_E_ARG, "saa_step_synced: bad argument");
+  if (!s->comm) return fail(SAA_E_STATE, "saa_step_synced: saa_comm_init has not been called");
+  if (s->pending) return fail(SAA_E_STATE, "saa_step_synced: a synchronised step is in flight");
+  HIP_TRY(hipSetDevice(s->device));
+  const size_t count = 3 * static_cast<size_t>(s->n_global_shared);
+  const int64_t width = 3 * static_cast<int64_t>(s->n_shared);
+  for (int32_t k = 0; k < nsteps; ++k) {
+    s->set_ramp();
+    saa::launch_fused_step(s->mesh, s->threads, s->lds_bytes, s->stream, s->dbuf[s->i0].p, s->dbuf[s->in_].p,
+                           s->dbuf[s->i1].p, s->iface, s->consts);
+    if (count > 0) {
+      const int rc = g_nccl.AllReduce(s->iface, s->iface, count, kNcclDouble, kNcclSum, s->comm, s->stream);
+      if (rc != 0) return fail(SAA_E_HIP, std::string("ncclAllReduce: ") + g_nccl.GetErrorString(rc));
+    }
+    saa::launch_iface_finish(s->mesh, s->shared, s->stream, s->dbuf[s->i0].p, s->dbuf[s->in_].p, s->dbuf[s->i1].p,
+                             s->iface, hist_dev ? hist_dev + (hist_row0 + k) * width : nullptr, s->consts);
+    s->rotate();
+    s->tn = s->tn + s->consts.dt;
+  }
   return check_launch();
 }
 

@@ -37,7 +37,8 @@ class PartitionedSolver:
 
     def __init__(self, points, cells, facets_or_dirichlet_nodes, epart, rank, world,
                  E=1e6, nu=0.3, rho=1.0, fz=0.5, alpha=0.5, gamma=0.9, device=0, process_group=None,
-                 tensor_device=None, solver_factory: Optional[Callable] = None, block_nodes=0, threads=0):
+                 tensor_device=None, solver_factory: Optional[Callable] = None, block_nodes=0, threads=0,
+                 native_exchange=True):
         import torch
 
         self.rank, self.world = int(rank), int(world)
@@ -71,6 +72,37 @@ class PartitionedSolver:
             self.solver.set_stream(torch.cuda.current_stream(self.tensor_device).cuda_stream)
         self.input_size = 3 * len(lay.shared_nodes)          # Online_predictor.py:126
         self.steps_done = 0
+        self.native_exchange = False
+        if native_exchange and self.world > 1 and self.tensor_device.type == "cuda":
+            self.native_exchange = self._init_native_exchange()
+
+    def _init_native_exchange(self) -> bool:
+        """Join an RCCL communicator owned by the C++ side (``saa_comm_init``); on any failure keep the
+        ``torch.distributed`` all-reduce.  All ranks take the same decision."""
+        import torch
+        import torch.distributed as dist
+
+        ok, uid = 1, bytes(128)
+        try:
+            if dist.get_backend(self.group) != "nccl" or not hasattr(self.solver, "comm_init"):
+                ok = 0
+            elif self.rank == 0:
+                uid = self.solver.comm_unique_id()
+        except Exception:  # noqa: BLE001
+            ok = 0
+        box = [uid]
+        dist.broadcast_object_list(box, src=0, group=self.group)
+        flag = torch.tensor([ok], device=self.tensor_device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+        if int(flag.item()) == 0:
+            return False
+        try:
+            self.solver.comm_init(box[0], self.rank, self.world)
+        except Exception:  # noqa: BLE001
+            ok = 0
+        flag = torch.tensor([ok], device=self.tensor_device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+        return int(flag.item()) == 1
 
     # -- the three kinds of step ---------------------------------------------------------------------
     def step_synced(self, nsteps=1, hist=None, hist_row0=0):
@@ -82,10 +114,13 @@ class PartitionedSolver:
             self.solver.step(nsteps)
             self.steps_done += nsteps
             return
-        for k in range(nsteps):
-            self.solver.step_begin()
-            dist.all_reduce(self.iface, group=self.group)
-            self.solver.step_finish(hist, hist_row0 + k)
+        if self.native_exchange:  # fused kernel, ncclAllReduce and finish kernel enqueued from C++
+            self.solver.step_synced(nsteps, hist, hist_row0)
+        else:
+            for k in range(nsteps):
+                self.solver.step_begin()
+                dist.all_reduce(self.iface, group=self.group)
+                self.solver.step_finish(hist, hist_row0 + k)
         self.steps_done += nsteps
 
     def step_local(self, nsteps=1):

@@ -159,6 +159,30 @@ class HipExplicitSolver:
     def step_finish(self, hist=None, hist_row=0):
         _lib.check(self._lib.saa_step_finish(self._h, _dev(hist), int(hist_row)))
 
+    # -- native exchange (RCCL from C++) ----------------------------------------------------------
+    @staticmethod
+    def rccl_library_path():
+        """The RCCL build PyTorch-ROCm already has in the process (one copy of the library only)."""
+        import os
+
+        import torch
+
+        path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        return path if os.path.exists(path) else "librccl.so"
+
+    def comm_unique_id(self):
+        buf = (C.c_uint8 * 128)()
+        _lib.check(self._lib.saa_comm_unique_id(self.rccl_library_path().encode(), buf))
+        return bytes(buf)
+
+    def comm_init(self, unique_id: bytes, rank: int, world: int):
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        _lib.check(self._lib.saa_comm_init(self._h, self.rccl_library_path().encode(), buf, int(rank), int(world)))
+
+    def step_synced(self, nsteps=1, hist=None, hist_row0=0):
+        """``nsteps`` synchronised steps entirely enqueued from C++ (needs :meth:`comm_init`)."""
+        _lib.check(self._lib.saa_step_synced(self._h, int(nsteps), _dev(hist), int(hist_row0)))
+
     def step_predicted(self, nsteps, table, table_row0=0, hist=None, hist_row0=0):
         _lib.check(self._lib.saa_step_predicted(self._h, int(nsteps), _dev(table), int(table_row0),
                                                 _dev(hist), int(hist_row0)))

@@ -113,3 +113,40 @@ def drivers_path(key, r):
     from synchronization_avoiding_algorithms_amd import drivers
 
     return drivers.PATHS[key].format(r=r)
+
+
+def test_native_rccl_exchange_single_rank(beam_coarse):
+    """saa_comm_init / saa_step_synced with a one-rank RCCL communicator: declared-shared nodes take the
+    begin -> ncclAllReduce -> finish route and must land where plain steps do."""
+    import synchronization_avoiding_algorithms_amd as saa
+    from synchronization_avoiding_algorithms_amd import fem_setup as fs
+    from synchronization_avoiding_algorithms_amd.mesh import clamp_nodes
+
+    mesh = beam_coarse
+    lmd, mu = fs.lame(1e6, 0.3)
+    layouts, _ = fs.build_layouts(mesh.tets, np.zeros(len(mesh.tets), dtype=int), 1, len(mesh.points),
+                                  clamp_nodes(mesh))
+    lay = layouts[0]
+    lumped, fpre = fs.lumped_mass_and_load(mesh.points, mesh.tets, 1.0, 0.5)
+    dt = fs.cfl_dt(mesh.points, mesh.tets, 1e6, 0.3, 1.0, 0.9)
+    shared = np.array([3, 17, 40, 41, 77, 100, 5, 60], dtype=np.int32)
+    args = (mesh.points[lay.nodes], lay.cells_local, lumped[lay.local_dof], fpre[lay.local_dof],
+            lay.dirichlet_dofs, lmd, mu, dt, 0.5)
+    plain = saa.HipExplicitSolver(*args)
+    synced = saa.HipExplicitSolver(*args, shared_local=shared, shared_slots=np.arange(8, dtype=np.int32)[::-1].copy(),
+                                   n_global_shared=10)  # two slots belong to "other ranks" and stay zero
+    iface = torch.zeros(30, dtype=torch.float64, device="cuda")
+    hist = torch.zeros((200, 24), dtype=torch.float64, device="cuda")
+    synced.set_interface_buffer(iface)
+    synced.set_stream(torch.cuda.current_stream().cuda_stream)
+    synced.comm_init(synced.comm_unique_id(), 0, 1)
+    plain.step(200)
+    synced.step_synced(200, hist, 0)
+    torch.cuda.synchronize()
+    a, b = plain.get_state()[0], synced.get_state()[0]
+    assert rel_l2(b, a) < 1e-13
+    dof = (3 * shared[:, None] + np.arange(3)[None, :]).ravel()
+    assert np.array_equal(hist[199].cpu().numpy(), b[dof, 0])
+    assert float(iface[24:].abs().max()) == 0.0  # foreign slots re-zeroed
+    plain.close()
+    synced.close()
