@@ -102,7 +102,7 @@ struct saa_solver {
   double tn = 0.0;
   // device storage
   DevBuf<saa::BlockDesc> blocks;
-  DevBuf<int32_t> halo_ids, tag, new_to_old, sh_node, sh_slot, sh_foreign;
+  DevBuf<int32_t> halo_ids, tag, new_to_old, sh_node, sh_slot, sh_foreign, slot_sidx;
   DevBuf<uint16_t> conn;
   DevBuf<double> xyz, mass, fext;
   DevBuf<double> dbuf[3];
@@ -124,7 +124,7 @@ struct saa_solver {
   void set_ramp() { consts.ramp = ramp ? (tn <= 1 ? tn : 1.0) : 1.0; }  // commons.py:7-11
   void release_all() {
     blocks.release(); halo_ids.release(); tag.release(); new_to_old.release(); sh_node.release();
-    sh_slot.release(); sh_foreign.release(); conn.release(); xyz.release(); mass.release(); fext.release();
+    sh_slot.release(); sh_foreign.release(); slot_sidx.release(); conn.release(); xyz.release(); mass.release(); fext.release();
     for (auto &b : dbuf) b.release();
     for (auto &b : scratch) b.release();
   }
@@ -329,6 +329,8 @@ int saa_create(const saa_problem *pb, saa_solver **out) {
     local_slot[sh_slot[i]] = 1;
     tag[sh_node[i]] |= saa::kTagShared | (sh_slot[i] << saa::kTagSlotShift);
   }
+  std::vector<int32_t> slot_sidx(pb->n_global_shared, -1);
+  for (int32_t i = 0; i < pb->n_shared; ++i) slot_sidx[sh_slot[i]] = i;
   for (int32_t g = 0; g < pb->n_global_shared; ++g)
     if (!local_slot[g]) foreign.push_back(g);
 
@@ -350,6 +352,7 @@ int saa_create(const saa_problem *pb, saa_solver **out) {
   CREATE_TRY(s->sh_node.upload(sh_node));
   CREATE_TRY(s->sh_slot.upload(sh_slot));
   CREATE_TRY(s->sh_foreign.upload(foreign));
+  CREATE_TRY(s->slot_sidx.upload(slot_sidx));
   for (auto &b : s->dbuf) {
     CREATE_TRY(b.alloc(3 * static_cast<size_t>(n)));
     CREATE_TRY(hipMemset(b.p, 0, 3 * static_cast<size_t>(n) * sizeof(double)));
@@ -363,6 +366,7 @@ int saa_create(const saa_problem *pb, saa_solver **out) {
   s->mesh.mass = s->mass.p;
   s->mesh.fext = s->fext.p;
   s->mesh.tag = s->tag.p;
+  s->mesh.slot_sidx = s->slot_sidx.p;
   s->mesh.lambda_ = pb->lambda_;
   s->mesh.mu = pb->mu;
   s->mesh.n_blocks = static_cast<int32_t>(plan.blocks.size());
@@ -486,7 +490,7 @@ int saa_step(saa_solver *s, int32_t nsteps) {
   for (int32_t k = 0; k < nsteps; ++k) {
     s->set_ramp();
     saa::launch_fused_step(s->mesh, s->threads, s->lds_bytes, s->stream, s->dbuf[s->i0].p, s->dbuf[s->in_].p,
-                           s->dbuf[s->i1].p, nullptr, s->consts);
+                           s->dbuf[s->i1].p, nullptr, nullptr, nullptr, s->consts);
     s->rotate();
     s->tn = s->tn + s->consts.dt;  // Data_prepare.py:235
   }
@@ -508,7 +512,7 @@ int saa_step_begin(saa_solver *s) {
   HIP_TRY(hipSetDevice(s->device));
   s->set_ramp();
   saa::launch_fused_step(s->mesh, s->threads, s->lds_bytes, s->stream, s->dbuf[s->i0].p, s->dbuf[s->in_].p,
-                         s->dbuf[s->i1].p, s->iface, s->consts);
+                         s->dbuf[s->i1].p, s->iface, nullptr, nullptr, s->consts);
   s->pending = true;
   return check_launch();
 }
@@ -565,7 +569,7 @@ int saa_step_synced(saa_solver *s, int32_t nsteps, double *hist_dev, int64_t his
   for (int32_t k = 0; k < nsteps; ++k) {
     s->set_ramp();
     saa::launch_fused_step(s->mesh, s->threads, s->lds_bytes, s->stream, s->dbuf[s->i0].p, s->dbuf[s->in_].p,
-                           s->dbuf[s->i1].p, s->iface, s->consts);
+                           s->dbuf[s->i1].p, s->iface, nullptr, nullptr, s->consts);
     if (count > 0) {
       const int rc = g_nccl.AllReduce(s->iface, s->iface, count, kNcclDouble, kNcclSum, s->comm, s->stream);
       if (rc != 0) return fail(SAA_E_HIP, std::string("ncclAllReduce: ") + g_nccl.GetErrorString(rc));
@@ -588,10 +592,10 @@ int saa_step_predicted(saa_solver *s, int32_t nsteps, const double *table_dev, i
   const int64_t width = 3 * static_cast<int64_t>(s->n_shared);
   for (int32_t k = 0; k < nsteps; ++k) {
     s->set_ramp();
+    // halo overwrite + history record are fused into the step kernel's epilogue (one launch per step)
     saa::launch_fused_step(s->mesh, s->threads, s->lds_bytes, s->stream, s->dbuf[s->i0].p, s->dbuf[s->in_].p,
-                           s->dbuf[s->i1].p, nullptr, s->consts);
-    saa::launch_halo_overwrite(s->shared, s->stream, table_dev + (table_row0 + k) * width, s->dbuf[s->i1].p,
-                               hist_dev ? hist_dev + (hist_row0 + k) * width : nullptr);
+                           s->dbuf[s->i1].p, nullptr, s->n_shared > 0 ? table_dev + (table_row0 + k) * width : nullptr,
+                           hist_dev ? hist_dev + (hist_row0 + k) * width : nullptr, s->consts);
     s->rotate();
     s->tn = s->tn + s->consts.dt;
   }

@@ -19,6 +19,7 @@ struct DeviceMesh {
   const double *mass;  // (3 n_nodes)
   const double *fext;  // (3 n_nodes) un-ramped
   const int32_t *tag;  // (n_nodes)
+  const int32_t *slot_sidx;  // (n_global_shared) interface slot -> index in the caller's shared list, -1 if foreign
   double lambda_, mu;
   int32_t n_blocks, n_nodes, max_local, max_owned, force_stride;
 };
@@ -39,7 +40,8 @@ struct SharedMap {
 
 hipError_t configure_kernels(int lds_bytes);
 void launch_fused_step(const DeviceMesh &m, int threads, int lds_bytes, hipStream_t st, const double *d0,
-                       const double *dn, double *d1, double *iface, const StepConsts &k);
+                       const double *dn, double *d1, double *iface, const double *table_row, double *hist_row,
+                       const StepConsts &k);
 void launch_fused_step_ablated(int variant, const DeviceMesh &m, int threads, int lds_bytes, hipStream_t st,
                                const double *d0, const double *dn, double *d1, const StepConsts &k);
 void launch_force_only(const DeviceMesh &m, int threads, int lds_bytes, hipStream_t st, const double *d,

@@ -222,7 +222,8 @@ constexpr int kPreConn = SAA_KPRE_CONN;
 // 2 = no indexed LDS reads, 3 = no staging loads, 4 = no update phase, 5 = no element phase.
 template <bool FORCE_ONLY, int ABLATE = 0>
 __global__ void __launch_bounds__(SAA_LB) fused_step_kernel(DeviceMesh m, const double *__restrict__ d0, const double *__restrict__ dn,
-                                  double *__restrict__ out, double *__restrict__ iface, StepConsts k) {
+                                  double *__restrict__ out, double *__restrict__ iface,
+                                  const double *__restrict__ table_row, double *__restrict__ hist_row, StepConsts k) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const BlockDesc bd = m.blocks[plan_block(blockIdx.x, m.n_blocks)];
   const int tid = threadIdx.x, nt = blockDim.x;
@@ -353,6 +354,12 @@ __global__ void __launch_bounds__(SAA_LB) fused_step_kernel(DeviceMesh m, const 
     if (iface != nullptr && (tag & kTagShared)) iface[3 * (int64_t)(tag >> kTagSlotShift) + c] = f;
     double v = cd_update_dof(f, fpre, mass, rec[6 * n + 3 + c], dnv, k);
     if (tag & (1 << c)) v = 0.0;  // d1[Local_Dirichlet] = 0   (Dynamic_solver.py:20)
+    if (table_row != nullptr && (tag & kTagShared)) {
+      // predicted phase: d1[loc_dof_shared] = prediction, recorded as history (Online_predictor.py:298,301)
+      const int64_t j = 3 * (int64_t)m.slot_sidx[tag >> kTagSlotShift] + c;
+      v = table_row[j];
+      if (hist_row != nullptr) hist_row[j] = v;
+    }
     out[base + i] = v;
   };
 #pragma unroll
@@ -365,9 +372,9 @@ __global__ void __launch_bounds__(SAA_LB) fused_step_kernel(DeviceMesh m, const 
 }
 
 template __global__ void fused_step_kernel<false>(DeviceMesh, const double *, const double *, double *,
-                                                   double *, StepConsts);
+                                                   double *, const double *, double *, StepConsts);
 template __global__ void fused_step_kernel<true>(DeviceMesh, const double *, const double *, double *,
-                                                  double *, StepConsts);
+                                                  double *, const double *, double *, StepConsts);
 
 // After the all-reduce: shared nodes get the update from the summed force (Dynamic_solver.py:26-32),
 // optional history record (Online_predictor.py:260); slots of shared nodes this rank does not hold
@@ -442,21 +449,23 @@ hipError_t configure_kernels(int lds_bytes) {
 }
 
 void launch_fused_step(const DeviceMesh &m, int threads, int lds_bytes, hipStream_t st, const double *d0,
-                       const double *dn, double *d1, double *iface, const StepConsts &k) {
+                       const double *dn, double *d1, double *iface, const double *table_row, double *hist_row,
+                       const StepConsts &k) {
   hipLaunchKernelGGL(fused_step_kernel<false>, dim3(m.n_blocks), dim3(threads), lds_bytes, st, m, d0, dn, d1,
-                     iface, k);
+                     iface, table_row, hist_row, k);
 }
 
 // Diagnostic only (tools/ablate.py): the step kernel with one phase removed; results are garbage.
 void launch_fused_step_ablated(int variant, const DeviceMesh &m, int threads, int lds_bytes, hipStream_t st,
                                const double *d0, const double *dn, double *d1, const StepConsts &k) {
   double *none = nullptr;
+  const double *cnone = nullptr;
 #define SAA_ABL(V)                                                                                         \
   case V:                                                                                                  \
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_step_kernel<false, V>),                \
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);                      \
     hipLaunchKernelGGL((fused_step_kernel<false, V>), dim3(m.n_blocks), dim3(threads), lds_bytes, st, m, d0, \
-                       dn, d1, none, k);                                                                   \
+                       dn, d1, none, cnone, none, k);                                                      \
     break;
   switch (variant) {
     SAA_ABL(0) SAA_ABL(1) SAA_ABL(2) SAA_ABL(3) SAA_ABL(4) SAA_ABL(5) SAA_ABL(6) SAA_ABL(7)
@@ -469,6 +478,7 @@ void launch_force_only(const DeviceMesh &m, int threads, int lds_bytes, hipStrea
                        double *f) {
   StepConsts k{};
   hipLaunchKernelGGL(fused_step_kernel<true>, dim3(m.n_blocks), dim3(threads), lds_bytes, st, m, d, d, f,
+                     static_cast<double *>(nullptr), static_cast<const double *>(nullptr),
                      static_cast<double *>(nullptr), k);
 }
 
