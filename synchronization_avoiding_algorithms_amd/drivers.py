@@ -135,13 +135,20 @@ def online_predictor(mesh, n_steps=100000, save_every=1, out_dir=".", rank=0, wo
     return path, store, hist
 
 
+def _has_gpu():
+    import torch
+
+    return torch.cuda.is_available()
+
+
 def _load_mesh(args):
     return structured_beam(args.synthetic) if args.synthetic else read_vtk(args.mesh)
 
 
 def main(argv=None):
     ap = argparse.ArgumentParser(prog="synchronization_avoiding_algorithms_amd.drivers")
-    ap.add_argument("command", choices=["data_prepare", "shared_extraction", "online_predictor"])
+    ap.add_argument("command", choices=["data_prepare", "shared_extraction", "model_training", "online_predictor"])
+    ap.add_argument("--epochs", type=int, default=None, help="model_training: override the epoch count")
     ap.add_argument("--mesh", default="Mesh_info/beam_coarse.vtk")
     ap.add_argument("--synthetic", type=int, default=0, help="use the 25n x n x n synthetic beam instead")
     ap.add_argument("--steps", type=int, default=100000)      # test_num, Data_prepare.py:49
@@ -159,6 +166,13 @@ def main(argv=None):
                                args.partition, device=local, verbose=True)
     elif args.command == "shared_extraction":
         path, _ = shared_extraction(args.out, rank)
+    elif args.command == "model_training":
+        from .training import train_rank_model
+
+        path, _, _ = train_rank_model(args.out, rank, device=f"cuda:{local}" if _has_gpu() else "cpu",
+                                      hidden_size=args.hidden_size, filter_size=args.filter_size,
+                                      n_past=args.n_past, n_future=args.n_future, num_epochs=args.epochs,
+                                      verbose=True)
     else:
         path, _, _ = online_predictor(_load_mesh(args), args.steps, args.save_every, args.out, rank, world,
                                       args.partition, device=local, n_past=args.n_past, n_future=args.n_future,

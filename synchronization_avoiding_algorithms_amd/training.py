@@ -1,0 +1,135 @@
+"""Per-rank training of the shared-node LSTM on PyTorch-ROCm.
+
+Counterpart of /root/reference ``Model_training.py`` + the training half of ``Tools/DNN_tools.py``
+(``model_train`` ``:103-165``, ``model_test`` ``:170-207``, windowing ``:284-313``, scaling ``:259-269``):
+one independent model per rank on that rank's shared-dof trajectory, Adam with exponentially decayed
+learning rate down to ``lr_min``, mini-batches of ``n_B`` windows, MSE on the recursively decoded
+``n_future`` steps in the [-1, 0] scaling, random 75/25 train/validation split, ``model.pth`` (a plain
+``state_dict``) at the path ``Online_predictor.py:139-140`` expects.  No gradient exchange between ranks.
+"""
+from __future__ import annotations
+
+import math
+import os
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import results_io as rio
+from .predictor import LSTM_encoder_decoder
+
+
+def windowed_dataset(displacement_shared, filter_size, n_past, n_future, cut_off, device="cpu"):
+    """``Dis_data_filtered_subset_coronary`` (``DNN_tools.py:284-313``) without the Python copy loop:
+    ``(groups, n_past, in)`` inputs and ``(groups, n_future, in)`` targets, fp32, on ``device``."""
+    data = np.asarray(displacement_shared).transpose()
+    data = data[0:int(cut_off * len(data)), :][0::filter_size, :]
+    series = torch.from_numpy(np.ascontiguousarray(data)).float().to(device)
+    groups = series.shape[0] - n_future - n_past + 1
+    if groups < 1:
+        raise ValueError("trajectory too short for one (n_past, n_future) window")
+    win = series.unfold(0, n_past + n_future, 1).permute(0, 2, 1)     # (groups, n_past+n_future, in)
+    return win[:, :n_past, :].contiguous(), win[:, n_past:, :].contiguous()
+
+
+def scale_to_zero_one(X, Y):
+    """``Scale_to_zero_one`` (``DNN_tools.py:259-269``): joint max/min, values mapped to [-1, 0]."""
+    smin, smax = min(X.min(), Y.min()), max(X.max(), Y.max())
+    return (X - smax) / (-smin + smax), (Y - smax) / (-smin + smax), smax.item(), smin.item()
+
+
+def _decode(model, X, n_future):
+    h, c = model.encoder(X)
+    inp = X[:, -1, :]
+    outs = []
+    for _ in range(n_future):
+        inp, h, c = model.decoder(inp, h, c)
+        outs.append(inp)
+    return torch.stack(outs, dim=1)
+
+
+def model_train(device, model, batches, criterion, optimizer, n_future):
+    """One epoch of recursive-decoding training (``DNN_tools.py:103-165``, 'recursive' method).
+    Returns (sum of batch losses, sum of R2 accuracies, sum of relative accuracies, model)."""
+    model.train()
+    loss_sum = r2_sum = rel_sum = 0.0
+    for X, Y in batches:
+        optimizer.zero_grad()
+        out = _decode(model, X, n_future)
+        loss = criterion(out, Y)
+        with torch.no_grad():
+            r2_sum += (1.0 - loss / criterion(Y, torch.mean(Y) + torch.zeros_like(Y))).item()
+            rel_sum += (1.0 - loss / criterion(Y, torch.zeros_like(Y))).item()
+        loss_sum += loss.item()
+        loss.backward()
+        optimizer.step()
+    return loss_sum, r2_sum, rel_sum, model
+
+
+def model_test(device, model, batches, criterion, n_future):
+    """Validation pass (``DNN_tools.py:170-207``)."""
+    model.eval()
+    loss_sum = r2_sum = rel_sum = 0.0
+    with torch.no_grad():
+        for X, Y in batches:
+            loss = criterion(_decode(model, X, n_future), Y)
+            loss_sum += loss.item()
+            r2_sum += (1.0 - loss / criterion(Y, torch.mean(Y) + torch.zeros_like(Y))).item()
+            rel_sum += (1.0 - loss / criterion(Y, torch.zeros_like(Y))).item()
+    return loss_sum, r2_sum, rel_sum
+
+
+def _batches(X, Y, batch_size, shuffle, generator=None):
+    idx = torch.randperm(X.shape[0], generator=generator, device="cpu") if shuffle else torch.arange(X.shape[0])
+    idx = idx.to(X.device)
+    return [(X[idx[i:i + batch_size]], Y[idx[i:i + batch_size]]) for i in range(0, X.shape[0], batch_size)]
+
+
+def train_rank_model(out_dir=".", rank=0, device=None, batch_size=10, learning_rate=5e-4, hidden_size=50,
+                     filter_size=150, cut_off=0.5, lr_min=5e-7, decay=0.998, T_portion=0.75, n_future=20, n_past=20,
+                     num_epochs=None, seed=None, verbose=False):
+    """``Model_training.py:17-181`` for one rank; returns ``(model_path, train_loss, validation_loss)``."""
+    from .drivers import PATHS
+
+    device = torch.device(device if device is not None else ("cuda" if torch.cuda.is_available() else "cpu"))
+    gen = None
+    if seed is not None:
+        torch.manual_seed(seed)
+        np.random.seed(seed)
+        gen = torch.Generator().manual_seed(seed)
+    shared = rio.load_int_list(os.path.join(out_dir, PATHS["shared"].format(r=rank)))
+    input_size = 3 * len(shared)
+    traj = rio.load_displacement(os.path.join(out_dir, PATHS["shared_traj"].format(r=rank)))
+    X, Y = windowed_dataset(traj, filter_size, n_past, n_future, cut_off, device)
+    X, Y, _, _ = scale_to_zero_one(X, Y)
+    model = LSTM_encoder_decoder(input_size, hidden_size, 2, True, 0.0, 0.0).to(device)
+    criterion = nn.MSELoss()
+    optimizer = torch.optim.Adam(model.parameters(), lr=learning_rate)
+    scheduler = torch.optim.lr_scheduler.LambdaLR(optimizer, lr_lambda=lambda epoch: decay ** epoch)
+    if num_epochs is None:
+        num_epochs = int(math.log(lr_min / learning_rate, decay))     # Model_training.py:65
+    n = X.shape[0]
+    train_idx = np.random.choice(n, size=int(T_portion * n), replace=False)
+    test_idx = np.setdiff1d(np.arange(n), train_idx)
+    Xtr, Ytr = X[torch.as_tensor(train_idx, device=device)], Y[torch.as_tensor(train_idx, device=device)]
+    Xte, Yte = X[torch.as_tensor(test_idx, device=device)], Y[torch.as_tensor(test_idx, device=device)]
+    train_loss, test_loss = [], []
+    for epoch in range(num_epochs):
+        tb = _batches(Xtr, Ytr, batch_size, True, gen)
+        vb = _batches(Xte, Yte, batch_size, False)
+        lt, r2, _, model = model_train(device, model, tb, criterion, optimizer, n_future)
+        lv, _, _ = model_test(device, model, vb, criterion, n_future) if vb else (float("nan"), 0, 0)
+        train_loss.append(lt / len(tb))
+        test_loss.append(lv / max(len(vb), 1))
+        if verbose and rank == 0 and epoch % 50 == 0:
+            print("Epoch: %d, mse training loss: %1.5e, R2 accuracy: %.3f, lr=%g"
+                  % (epoch, train_loss[-1], r2 / len(tb), optimizer.param_groups[0]["lr"]))
+        scheduler.step()
+    path = os.path.join(out_dir, PATHS["model"].format(r=rank, nB=batch_size, nH=hidden_size, lr=learning_rate,
+                                                       ns=filter_size))
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    np.savetxt(os.path.join(os.path.dirname(path), "train_loss.csv"), train_loss, delimiter=",")
+    np.savetxt(os.path.join(os.path.dirname(path), "test_loss.csv"), test_loss, delimiter=",")
+    torch.save(model.state_dict(), path)
+    return path, train_loss, test_loss
