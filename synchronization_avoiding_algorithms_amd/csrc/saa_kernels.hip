@@ -1,15 +1,19 @@
 // gfx950 (MI355X / CDNA4) kernels of the explicit linear-tet elastodynamics step.
 //
 // One fused kernel per time step (fused_step_kernel): a workgroup owns a contiguous block of nodes,
-//   1. stages coordinates + displacement d^n of its owned and halo nodes in LDS (48-byte records),
-//   2. evaluates every element touching an owned node, matrix-free:
+//   1. stages coordinates + displacement d^n of its owned and halo nodes in LDS (48-byte records); halo
+//      gathers and the update operands travel in registers while the interior elements already run,
+//   2. evaluates every element touching an owned node, matrix-free, two face-adjacent tets per lane
+//      ("items", saa_plan.h: 5 node records and 5 force flushes for two elements):
 //          f_a = (detJ/6) * sigma(grad u) * gradN_a        [= K_e d restricted to node a]
 //      (closed form of Local_K_coronary, /root/reference Tools/Mat_construction.py:79-119, with the
 //      B-matrix convention of :99-104; the 4-point rule of Tools/Qudrature.py:7-12 is exact for the
 //      constant integrand, weights sum to 1/6) and accumulates f_a of OWNED nodes in LDS
 //      (ds_add_f64) - no global atomics, no force vector in HBM,
 //   3. applies the damped central-difference update of Tools/Dynamic_solver.py:13-20 to its owned
-//      dofs in the reference's association order (no FMA contraction) and writes d^(n+1).
+//      dofs in the reference's association order (no FMA contraction) and writes d^(n+1); shared nodes
+//      additionally publish their partial force (synchronised mode) or take the LSTM prediction and
+//      record it as history (sync-avoiding mode, Online_predictor.py:298-301).
 // The same kernel in FORCE_ONLY mode writes f_int instead (backs LocalK.dot, Dynamic_solver.py:12).
 //
 // Bandwidth-bound gather/scatter in fp64: MFMA is not used (and fp64 MFMA has the vector rate on
@@ -303,7 +307,11 @@ __global__ void __launch_bounds__(SAA_LB) fused_step_kernel(DeviceMesh m, const 
     }
   }
   // first boundary sweep's connectivity: issued now, consumed after the halo records are in LDS
-  const int e_b0 = bd.n_interior + tid;
+  // Wave balance: a wave's items are a serial chain, so the workgroup is as slow as its busiest wave.
+  // The interior list fills waves 0,1,2,.. in 64-item chunks; the boundary list continues with the NEXT
+  // wave instead of starting at wave 0 again (39 chunks over 16 waves: at most 3 per wave instead of 4).
+  const int shift = (((bd.n_interior + 63) >> 6) % (nt >> 6)) << 6;
+  const int e_b0 = bd.n_interior + (tid >= shift ? tid - shift : tid - shift + nt);
   uint4 bcur = conn[min(e_b0, max(bd.n_elem - 1, 0))];
 
   // ---- 4. halo records -> LDS --------------------------------------------------------------------
