@@ -56,7 +56,7 @@ def main():
     t1 = time.time()
     drivers.shared_extraction(args.out, rank)
     path, tl, vl = training.train_rank_model(args.out, rank, device=f"cuda:{local}", hidden_size=args.hidden_size,
-                                             filter_size=args.filter_size, num_epochs=args.epochs, seed=rank)
+                                             filter_size=args.filter_size, num_epochs=args.epochs, seed=rank, verbose=True)
     barrier()
     t2 = time.time()
     _, modeled, _ = drivers.online_predictor(mesh, args.steps, 1, args.out, rank, world, device=local,
