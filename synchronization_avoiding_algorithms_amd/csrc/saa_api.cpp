@@ -649,11 +649,15 @@ int saa_debug_time_ablated(saa_solver *s, int32_t variant, int32_t nsteps, doubl
   hipEvent_t a, b;
   HIP_TRY(hipEventCreate(&a));
   HIP_TRY(hipEventCreate(&b));
+  // variant 8 writes 12 stamps per wave into scratch[0] (needs 12*8*waves bytes <= 24*n_nodes: checked)
+  if (int rc = ensure_scratch(s, 1)) return rc;
+  if (variant == 8 && 12ull * s->mesh.n_blocks * (s->threads / 64) > 3ull * s->plan.n_nodes)
+    return fail(SAA_E_ARG, "saa_debug_time_ablated: scratch too small for stamps");
   s->set_ramp();
   HIP_TRY(hipEventRecord(a, s->stream));
   for (int32_t k = 0; k < nsteps; ++k)
     saa::launch_fused_step_ablated(variant, s->mesh, s->threads, s->lds_bytes, s->stream, s->dbuf[s->i0].p,
-                                   s->dbuf[s->in_].p, s->dbuf[s->i1].p, s->consts);
+                                   s->dbuf[s->in_].p, s->dbuf[s->i1].p, s->consts, s->scratch[0].p);
   HIP_TRY(hipEventRecord(b, s->stream));
   HIP_TRY(hipEventSynchronize(b));
   float ms = 0.f;
@@ -662,6 +666,14 @@ int saa_debug_time_ablated(saa_solver *s, int32_t variant, int32_t nsteps, doubl
   (void)hipEventDestroy(a);
   (void)hipEventDestroy(b);
   return check_launch();
+}
+
+// Diagnostic: copies the stamps of the last variant-8 launch to the host (n = 12 * blocks * waves values).
+int saa_debug_read_stamps(saa_solver *s, unsigned long long *out, int64_t n) {
+  if (!s || !out || !s->scratch[0].p) return fail(SAA_E_ARG, "saa_debug_read_stamps: bad argument");
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  HIP_TRY(hipMemcpy(out, s->scratch[0].p, n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  return SAA_OK;
 }
 
 }  // extern "C"

@@ -43,7 +43,7 @@ void launch_fused_step(const DeviceMesh &m, int threads, int lds_bytes, hipStrea
                        const double *dn, double *d1, double *iface, const double *table_row, double *hist_row,
                        const StepConsts &k);
 void launch_fused_step_ablated(int variant, const DeviceMesh &m, int threads, int lds_bytes, hipStream_t st,
-                               const double *d0, const double *dn, double *d1, const StepConsts &k);
+                               const double *d0, const double *dn, double *d1, const StepConsts &k, double *dbg);
 void launch_force_only(const DeviceMesh &m, int threads, int lds_bytes, hipStream_t st, const double *d,
                        double *f);
 void launch_iface_finish(const DeviceMesh &m, const SharedMap &sh, hipStream_t st, const double *d0,

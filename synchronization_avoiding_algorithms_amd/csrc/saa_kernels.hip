@@ -151,9 +151,18 @@ __device__ __forceinline__ Vec3 neg_sum3(const Vec3 &a, const Vec3 &b, const Vec
   return {-(a.x + b.x + c.x), -(a.y + b.y + c.y), -(a.z + b.z + c.z)};
 }
 
+// In-kernel stamp (diagnostic build ABLATE == 8 only): shader clock after all outstanding LDS work has drained.
+__device__ __forceinline__ unsigned long long stamp() {
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+
 template <int ABLATE>
 __device__ __forceinline__ void item_forces(const uint4 w, const double *rec, double *acc, int fstride, int n_owned,
-                                            double lam, double mu, int tid, double &sink) {
+                                            double lam, double mu, int tid, double &sink, unsigned long long *T = nullptr) {
   Item it = unpack(w);
   if (it.null) return;  // idle lane left by the LDS packing (saa_plan.cpp)
   if (ABLATE == 2) {  // every lane reads its own fixed records: no index-dependent LDS traffic
@@ -171,9 +180,15 @@ __device__ __forceinline__ void item_forces(const uint4 w, const double *rec, do
             g3.x + g3.y + g3.z;
     return;
   }
+  unsigned long long t0 = 0, t1 = 0;
+  if (ABLATE == 8) t0 = stamp();
   const Rec rp = load_rec(rec, it.p), rq = load_rec(rec, it.q), rr = load_rec(rec, it.r);
   {
     const Rec ra = load_rec(rec, it.a);
+    if (ABLATE == 8) {
+      t1 = stamp();
+      T[0] += t1 - t0;  // 12 reads: issue + arrival
+    }
     if (ABLATE == 7) {  // LDS only: reads and atomics without the element arithmetic
       fa = add3(ra.x, ra.u); fp = add3(rp.x, rp.u); fq = add3(rq.x, rq.u); fr = add3(rr.x, rr.u);
     } else {
@@ -182,10 +197,18 @@ __device__ __forceinline__ void item_forces(const uint4 w, const double *rec, do
       fp = neg_sum3(fa, fr, fq);
     }
   }
+  if (ABLATE == 8) {
+    t0 = stamp();
+    T[1] += t0 - t1;  // VALU of tet A
+  }
   if (ABLATE != 1) flush(acc, fstride, it.a, n_owned, fa);
   else sink += fa.x + fa.y + fa.z;
   if (it.pair) {
     const Rec rb = load_rec(rec, it.b);
+    if (ABLATE == 8) {
+      t1 = stamp();
+      T[2] += t1 - t0;  // 3 atomics + 3 reads round trip
+    }
     if (ABLATE == 7) {
       fb = add3(rb.x, rb.u);
     } else {
@@ -195,6 +218,10 @@ __device__ __forceinline__ void item_forces(const uint4 w, const double *rec, do
       fp = add3(fp, neg_sum3(fb, gq, gr));
       fq = add3(fq, gq);
       fr = add3(fr, gr);
+    }
+    if (ABLATE == 8) {
+      t0 = stamp();
+      T[3] += t0 - t1;  // VALU of tet B
     }
     if (ABLATE != 1) flush(acc, fstride, it.b, n_owned, fb);
     else sink += fb.x + fb.y + fb.z;
@@ -206,6 +233,7 @@ __device__ __forceinline__ void item_forces(const uint4 w, const double *rec, do
   flush(acc, fstride, it.p, n_owned, fp);
   flush(acc, fstride, it.q, n_owned, fq);
   flush(acc, fstride, it.r, n_owned, fr);
+  if (ABLATE == 8) T[4] += stamp() - t0;  // remaining atomics: issue + drain
 }
 
 // Per-thread prefetch depth (dofs): the update operands of the first kPreOwn*blockDim owned dofs and
@@ -239,6 +267,8 @@ __global__ void __launch_bounds__(SAA_LB) fused_step_kernel(DeviceMesh m, const 
   const int32_t *hid = m.halo_ids + bd.halo_off;
 
   // ---- 0. interior connectivity and halo ids first (see kPreConn) ------------------------------
+  unsigned long long T[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tk = 0;
+  if (ABLATE == 8) tk = stamp();
   const uint4 *conn = m.conn + bd.elem_off;
   uint4 cpre[kPreConn];
 #pragma unroll
@@ -286,6 +316,11 @@ __global__ void __launch_bounds__(SAA_LB) fused_step_kernel(DeviceMesh m, const 
     }
   }
   lds_barrier();
+  if (ABLATE == 8) {
+    const unsigned long long t = stamp();
+    T[6] = t - tk;  // staging up to and including the first barrier
+    tk = t;
+  }
 
   // ---- 3. interior elements (all four nodes owned) --------------------------------------------
   double sink = 0.0;
@@ -293,7 +328,7 @@ __global__ void __launch_bounds__(SAA_LB) fused_step_kernel(DeviceMesh m, const 
 #pragma unroll
     for (int j = 0; j < kPreConn; ++j)
       if (tid + j * nt < bd.n_interior)
-        item_forces<ABLATE>(cpre[j], rec, acc, fstride, bd.n_owned, m.lambda_, m.mu, tid, sink);
+        item_forces<ABLATE>(cpre[j], rec, acc, fstride, bd.n_owned, m.lambda_, m.mu, tid, sink, T);
     // (rare) further interior sweeps, software-pipelined: the next connectivity entry is in flight while
     // the current element computes - a dependent global load per sweep would expose its L2 latency
     if (tid + kPreConn * nt < bd.n_interior) {
@@ -301,10 +336,15 @@ __global__ void __launch_bounds__(SAA_LB) fused_step_kernel(DeviceMesh m, const 
       uint4 cur = conn[tid + kPreConn * nt];
       for (int e = tid + kPreConn * nt; e < bd.n_interior; e += nt) {
         const uint4 nxt = conn[min(e + nt, last)];
-        item_forces<ABLATE>(cur, rec, acc, fstride, bd.n_owned, m.lambda_, m.mu, tid, sink);
+        item_forces<ABLATE>(cur, rec, acc, fstride, bd.n_owned, m.lambda_, m.mu, tid, sink, T);
         cur = nxt;
       }
     }
+  }
+  if (ABLATE == 8) {
+    const unsigned long long t = stamp();
+    T[7] = t - tk;  // interior loop
+    tk = t;
   }
   // first boundary sweep's connectivity: issued now, consumed after the halo records are in LDS
   // Wave balance: a wave's items are a serial chain, so the workgroup is as slow as its busiest wave.
@@ -332,17 +372,32 @@ __global__ void __launch_bounds__(SAA_LB) fused_step_kernel(DeviceMesh m, const 
   }
   lds_barrier();
 
+  if (ABLATE == 8) {
+    const unsigned long long t = stamp();
+    T[8] = t - tk;  // halo records to LDS + barrier
+    tk = t;
+  }
   // ---- 5. boundary elements (at least one halo node) ----------------------------------------------
   if (ABLATE != 5) {
     const int last = bd.n_elem - 1;
     for (int e = e_b0; e < bd.n_elem; e += nt) {
       const uint4 nxt = conn[min(e + nt, last)];
-      item_forces<ABLATE>(bcur, rec, acc, fstride, bd.n_owned, m.lambda_, m.mu, tid, sink);
+      item_forces<ABLATE>(bcur, rec, acc, fstride, bd.n_owned, m.lambda_, m.mu, tid, sink, T);
       bcur = nxt;
     }
   }
   if ((ABLATE == 1 || ABLATE == 6) && sink == 12345.678) acc[0] = sink;
+  if (ABLATE == 8) {
+    const unsigned long long t = stamp();
+    T[9] = t - tk;  // boundary loop
+    tk = t;
+  }
   lds_barrier();
+  if (ABLATE == 8) {
+    const unsigned long long t = stamp();
+    T[10] = t - tk;  // waiting for the slowest wave
+    tk = t;
+  }
   if (ABLATE == 4) {
     if (tid == 0) out[base] = acc[0];
     return;
@@ -362,7 +417,7 @@ __global__ void __launch_bounds__(SAA_LB) fused_step_kernel(DeviceMesh m, const 
     if (iface != nullptr && (tag & kTagShared)) iface[3 * (int64_t)(tag >> kTagSlotShift) + c] = f;
     double v = cd_update_dof(f, fpre, mass, rec[6 * n + 3 + c], dnv, k);
     if (tag & (1 << c)) v = 0.0;  // d1[Local_Dirichlet] = 0   (Dynamic_solver.py:20)
-    if (table_row != nullptr && (tag & kTagShared)) {
+    if (ABLATE != 8 && table_row != nullptr && (tag & kTagShared)) {
       // predicted phase: d1[loc_dof_shared] = prediction, recorded as history (Online_predictor.py:298,301)
       const int64_t j = 3 * (int64_t)m.slot_sidx[tag >> kTagSlotShift] + c;
       v = table_row[j];
@@ -377,6 +432,14 @@ __global__ void __launch_bounds__(SAA_LB) fused_step_kernel(DeviceMesh m, const 
   }
   for (int i = tid + kPreOwn * nt; i < n_own3; i += nt)
     finish(i, m.mass[base + i], m.fext[base + i], dn[base + i], m.tag[bd.node_start + i / 3]);
+  if (ABLATE == 8) {  // stamps leave through a buffer of their own (passed in place of the history row)
+    T[11] = stamp() - tk;  // update phase
+    if ((tid & 63) == 0) {
+      unsigned long long *dbg = reinterpret_cast<unsigned long long *>(hist_row) +
+                                12 * ((size_t)blockIdx.x * (nt >> 6) + (tid >> 6));
+      for (int j = 0; j < 12; ++j) dbg[j] = T[j];
+    }
+  }
 }
 
 template __global__ void fused_step_kernel<false>(DeviceMesh, const double *, const double *, double *,
@@ -465,7 +528,7 @@ void launch_fused_step(const DeviceMesh &m, int threads, int lds_bytes, hipStrea
 
 // Diagnostic only (tools/ablate.py): the step kernel with one phase removed; results are garbage.
 void launch_fused_step_ablated(int variant, const DeviceMesh &m, int threads, int lds_bytes, hipStream_t st,
-                               const double *d0, const double *dn, double *d1, const StepConsts &k) {
+                               const double *d0, const double *dn, double *d1, const StepConsts &k, double *dbg) {
   double *none = nullptr;
   const double *cnone = nullptr;
 #define SAA_ABL(V)                                                                                         \
@@ -473,10 +536,10 @@ void launch_fused_step_ablated(int variant, const DeviceMesh &m, int threads, in
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_step_kernel<false, V>),                \
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);                      \
     hipLaunchKernelGGL((fused_step_kernel<false, V>), dim3(m.n_blocks), dim3(threads), lds_bytes, st, m, d0, \
-                       dn, d1, none, cnone, none, k);                                                      \
+                       dn, d1, none, cnone, V == 8 ? dbg : none, k);                                       \
     break;
   switch (variant) {
-    SAA_ABL(0) SAA_ABL(1) SAA_ABL(2) SAA_ABL(3) SAA_ABL(4) SAA_ABL(5) SAA_ABL(6) SAA_ABL(7)
+    SAA_ABL(0) SAA_ABL(1) SAA_ABL(2) SAA_ABL(3) SAA_ABL(4) SAA_ABL(5) SAA_ABL(6) SAA_ABL(7) SAA_ABL(8)
     default: break;
   }
 #undef SAA_ABL
