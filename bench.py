@@ -53,6 +53,24 @@ def build_rank_solver(mesh, n_parts, rank, device, block_nodes=0, threads=0):
     return sol, lay, gshared, dt
 
 
+def measured_copy_bandwidth(n_bytes=1 << 30, reps=10):
+    """Device-to-device copy rate (read + write bytes per second) of this GPU: the practical HBM ceiling
+    SURVEY.md section 8(d) asks to report next to the nominal 8 TB/s."""
+    import torch
+
+    a = torch.empty(n_bytes // 8, dtype=torch.float64, device="cuda").normal_()
+    b = torch.empty_like(a)
+    b.copy_(a)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    return 2.0 * n_bytes * reps / (e0.elapsed_time(e1) * 1e-3)
+
+
 def cpu_baseline_and_parity(sample_n=10, steps=12000, parity_steps=3000):
     """Oracle (CPU port of the reference's per-step operations) timed on a bounded sample; the GPU steps the
     same sample for the parity figure."""
@@ -219,6 +237,9 @@ def main():
                            "kernel": "fused_step_kernel<false>", "avg_launch_us": 1e3 * ms / k,
                            "algorithmic_bytes_per_launch": b_alg,
                            "algorithmic_bytes_per_element_update": b_alg / ne_total}
+        copy_bw = measured_copy_bandwidth()
+        out["roofline"]["measured_copy_GBps"] = copy_bw / 1e9
+        out["roofline"]["frac_of_measured_copy"] = achieved / copy_bw
         if not args.no_cpu_baseline:
             out["cpu_baseline"], out["parity"] = cpu_baseline_and_parity()
     sol.close()

@@ -103,7 +103,7 @@ struct saa_solver {
   // device storage
   DevBuf<saa::BlockDesc> blocks;
   DevBuf<int32_t> halo_ids, tag, new_to_old, sh_node, sh_slot, sh_foreign, slot_sidx;
-  DevBuf<uint16_t> conn;
+  DevBuf<uint64_t> conn;
   DevBuf<double> xyz, mass, fext;
   DevBuf<double> dbuf[3];
   DevBuf<double> scratch[4];
@@ -338,8 +338,8 @@ int saa_create(const saa_problem *pb, saa_solver **out) {
     // one entry of padding: the kernel's clamped prefetches read index 0 of possibly empty lists
     std::vector<int32_t> halo_padded(plan.halo_ids);
     halo_padded.push_back(0);
-    std::vector<uint16_t> conn_padded(plan.conn);
-    conn_padded.insert(conn_padded.end(), 8, 0);
+    std::vector<uint64_t> conn_padded(plan.conn_packed);
+    conn_padded.push_back(0);
     CREATE_TRY(s->halo_ids.upload(halo_padded));
     CREATE_TRY(s->conn.upload(conn_padded));
   }
@@ -361,7 +361,7 @@ int saa_create(const saa_problem *pb, saa_solver **out) {
 
   s->mesh.blocks = s->blocks.p;
   s->mesh.halo_ids = s->halo_ids.p;
-  s->mesh.conn = reinterpret_cast<const uint4 *>(s->conn.p);
+  s->mesh.conn = reinterpret_cast<const uint2 *>(s->conn.p);
   s->mesh.xyz = s->xyz.p;
   s->mesh.mass = s->mass.p;
   s->mesh.fext = s->fext.p;

@@ -14,7 +14,7 @@ constexpr int kTagSlotShift = 8;
 struct DeviceMesh {
   const BlockDesc *blocks;
   const int32_t *halo_ids;
-  const uint4 *conn;   // work items: 8 x uint16 (a, p, q, r, b, flag, -, -), see saa_plan.h
+  const uint2 *conn;   // work items packed in 64 bits: 5 x 12-bit node index + 2-bit flag, see saa_plan.h
   const double *xyz;   // (n_nodes,3) internal order
   const double *mass;  // (3 n_nodes)
   const double *fext;  // (3 n_nodes) un-ramped

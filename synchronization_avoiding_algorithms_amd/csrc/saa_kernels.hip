@@ -128,8 +128,11 @@ struct Item {
   unsigned a, p, q, r, b;
   bool pair, null;
 };
-__device__ __forceinline__ Item unpack(const uint4 w) {
-  return {w.x & 0xffffu, w.x >> 16, w.y & 0xffffu, w.y >> 16, w.z & 0xffffu, (w.z >> 16) == 1u, (w.z >> 16) == 2u};
+// packed item (saa_plan.h): 5 x 12-bit block-local node index, flag in bits 60-61
+__device__ __forceinline__ Item unpack(const uint2 w) {
+  const unsigned flag = w.y >> 28;
+  return {w.x & 0xfffu, (w.x >> 12) & 0xfffu, (w.x >> 24) | ((w.y & 0xfu) << 8), (w.y >> 4) & 0xfffu,
+          (w.y >> 16) & 0xfffu, flag == 1u, flag == 2u};
 }
 struct Rec {
   Vec3 x, u;
@@ -161,7 +164,7 @@ __device__ __forceinline__ unsigned long long stamp() {
 }
 
 template <int ABLATE>
-__device__ __forceinline__ void item_forces(const uint4 w, const double *rec, double *acc, int fstride, int n_owned,
+__device__ __forceinline__ void item_forces(const uint2 w, const double *rec, double *acc, int fstride, int n_owned,
                                             double lam, double mu, int tid, double &sink, unsigned long long *T = nullptr) {
   Item it = unpack(w);
   if (it.null) return;  // idle lane left by the LDS packing (saa_plan.cpp)
@@ -269,8 +272,8 @@ __global__ void __launch_bounds__(SAA_LB) fused_step_kernel(DeviceMesh m, const 
   // ---- 0. interior connectivity and halo ids first (see kPreConn) ------------------------------
   unsigned long long T[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tk = 0;
   if (ABLATE == 8) tk = stamp();
-  const uint4 *conn = m.conn + bd.elem_off;
-  uint4 cpre[kPreConn];
+  const uint2 *conn = m.conn + bd.elem_off;
+  uint2 cpre[kPreConn];
 #pragma unroll
   // All prefetch loads are UNCONDITIONAL with clamped (always valid) indices: loads under a
   // divergent branch make hipcc fall back to s_waitcnt vmcnt(0) at the first use (the plan pads
@@ -333,9 +336,9 @@ __global__ void __launch_bounds__(SAA_LB) fused_step_kernel(DeviceMesh m, const 
     // the current element computes - a dependent global load per sweep would expose its L2 latency
     if (tid + kPreConn * nt < bd.n_interior) {
       const int last = bd.n_elem - 1;
-      uint4 cur = conn[tid + kPreConn * nt];
+      uint2 cur = conn[tid + kPreConn * nt];
       for (int e = tid + kPreConn * nt; e < bd.n_interior; e += nt) {
-        const uint4 nxt = conn[min(e + nt, last)];
+        const uint2 nxt = conn[min(e + nt, last)];
         item_forces<ABLATE>(cur, rec, acc, fstride, bd.n_owned, m.lambda_, m.mu, tid, sink, T);
         cur = nxt;
       }
@@ -352,7 +355,7 @@ __global__ void __launch_bounds__(SAA_LB) fused_step_kernel(DeviceMesh m, const 
   // wave instead of starting at wave 0 again (39 chunks over 16 waves: at most 3 per wave instead of 4).
   const int shift = (((bd.n_interior + 63) >> 6) % (nt >> 6)) << 6;
   const int e_b0 = bd.n_interior + (tid >= shift ? tid - shift : tid - shift + nt);
-  uint4 bcur = conn[min(e_b0, max(bd.n_elem - 1, 0))];
+  uint2 bcur = conn[min(e_b0, max(bd.n_elem - 1, 0))];
 
   // ---- 4. halo records -> LDS --------------------------------------------------------------------
 #pragma unroll
@@ -381,7 +384,7 @@ __global__ void __launch_bounds__(SAA_LB) fused_step_kernel(DeviceMesh m, const 
   if (ABLATE != 5) {
     const int last = bd.n_elem - 1;
     for (int e = e_b0; e < bd.n_elem; e += nt) {
-      const uint4 nxt = conn[min(e + nt, last)];
+      const uint2 nxt = conn[min(e + nt, last)];
       item_forces<ABLATE>(bcur, rec, acc, fstride, bd.n_owned, m.lambda_, m.mu, tid, sink, T);
       bcur = nxt;
     }

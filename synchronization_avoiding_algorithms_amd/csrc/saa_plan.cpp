@@ -502,6 +502,13 @@ bool build_once(int32_t n_nodes, int32_t n_elems, const double *xyz, const int32
     plan.n_pairs += n_paired[b];
   }
   plan.n_items = total_items;
+  plan.conn_packed.resize(static_cast<size_t>(total_items));
+  for (int64_t i = 0; i < total_items; ++i) {
+    const uint16_t *it = &plan.conn[8 * static_cast<size_t>(i)];
+    uint64_t w = static_cast<uint64_t>(it[5] & 3u) << 60;
+    for (int a = 0; a < 5; ++a) w |= static_cast<uint64_t>(it[a] & 0xfffu) << (12 * a);
+    plan.conn_packed[i] = w;
+  }
   PackStats tot;
   for (const auto &st : stats) {
     tot.read_mult += st.read_mult;

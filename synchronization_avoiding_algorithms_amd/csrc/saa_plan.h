@@ -47,6 +47,9 @@ struct Plan {
   // elements instead of 8 + 8); flag = 0: the single tet (a, p, q, r), b = p as a harmless dummy;
   // flag = 2: null item (an idle lane left by the LDS packing).
   std::vector<uint16_t> conn;
+  // The same items as the device reads them: 64 bits each, node indices in 12-bit fields (a at bit 0, p 12,
+  // q 24, r 36, b 48), flag in bits 60-61 - 8 bytes of connectivity per TWO elements.
+  std::vector<uint64_t> conn_packed;
   int64_t n_items = 0, n_pairs = 0;
   double lds_conflict_factor = 1.0; // mean over (half-wave, vertex slot) of the worst bank multiplicity
   int32_t max_owned = 0, max_local = 0;
@@ -55,7 +58,7 @@ struct Plan {
 
 // Largest number of block-local nodes (owned + halo) a workgroup may stage; bounded by the 16-bit
 // local indices and by the LDS budget the kernels are compiled for.
-constexpr int32_t kMaxLocalNodes = 2730;  // 2730 * 48 B = 128 KiB of node records
+constexpr int32_t kMaxLocalNodes = 2730;  // 2730 * 48 B = 128 KiB of node records; < 4096 (12-bit item fields)
 constexpr int32_t kDefaultBlockNodes = 384;
 
 // Builds the plan; on failure returns false and fills err.  block_nodes <= 0 selects the default.
