@@ -17,6 +17,8 @@ struct DeviceMesh {
   const uint2 *conn;   // work items packed in 64 bits: 5 x 12-bit node index + 2-bit flag, see saa_plan.h
   const double *xyz;   // (n_nodes,3) internal order
   const double *mass;  // (3 n_nodes)
+  const double *mass_node;  // (n_nodes) when every node has one mass for its three dofs (the reference's
+                            // lumped mass always does), else nullptr: saves 16 B per node and step
   const double *fext;  // (3 n_nodes) un-ramped
   const int32_t *tag;  // (n_nodes)
   const int32_t *slot_sidx;  // (n_global_shared) interface slot -> index in the caller's shared list, -1 if foreign
