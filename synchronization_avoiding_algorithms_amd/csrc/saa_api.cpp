@@ -104,7 +104,7 @@ struct saa_solver {
   DevBuf<saa::BlockDesc> blocks;
   DevBuf<int32_t> halo_ids, tag, new_to_old, sh_node, sh_slot, sh_foreign, slot_sidx;
   DevBuf<uint64_t> conn;
-  DevBuf<double> xyz, mass, fext, mass_node;
+  DevBuf<double> xyz, mass, fext, mass_node, fext_yz;
   DevBuf<double> dbuf[3];
   DevBuf<double> scratch[4];
   int i0 = 0, in_ = 1, i1 = 2;  // dbuf indices of d^n, d^(n-1), d^(n+1)
@@ -124,7 +124,7 @@ struct saa_solver {
   void set_ramp() { consts.ramp = ramp ? (tn <= 1 ? tn : 1.0) : 1.0; }  // commons.py:7-11
   void release_all() {
     blocks.release(); halo_ids.release(); tag.release(); new_to_old.release(); sh_node.release();
-    sh_slot.release(); sh_foreign.release(); slot_sidx.release(); conn.release(); xyz.release(); mass.release(); fext.release(); mass_node.release();
+    sh_slot.release(); sh_foreign.release(); slot_sidx.release(); conn.release(); xyz.release(); mass.release(); fext.release(); mass_node.release(); fext_yz.release();
     for (auto &b : dbuf) b.release();
     for (auto &b : scratch) b.release();
   }
@@ -222,6 +222,23 @@ int refresh_nodal_mass(saa_solver *s, const std::vector<double> &mass_internal) 
   if (!s->mass_node.p) HIP_TRY(s->mass_node.alloc(n));
   HIP_TRY(hipMemcpy(s->mass_node.p, mn.data(), n * sizeof(double), hipMemcpyHostToDevice));
   s->mesh.mass_node = s->mass_node.p;
+  return SAA_OK;
+}
+
+// Per-node copy of the load if it has the form (0, v, v) on every node (exact test), else none.
+int refresh_nodal_load(saa_solver *s, const std::vector<double> &f_internal) {
+  const int32_t n = s->plan.n_nodes;
+  bool yz = true;
+  for (int32_t i = 0; i < n && yz; ++i)
+    yz = f_internal[3 * static_cast<size_t>(i)] == 0.0 && !std::signbit(f_internal[3 * static_cast<size_t>(i)]) &&
+         f_internal[3 * static_cast<size_t>(i) + 1] == f_internal[3 * static_cast<size_t>(i) + 2];
+  s->mesh.fext_yz = nullptr;
+  if (!yz) return SAA_OK;
+  std::vector<double> v(n);
+  for (int32_t i = 0; i < n; ++i) v[i] = f_internal[3 * static_cast<size_t>(i) + 1];
+  if (!s->fext_yz.p) HIP_TRY(s->fext_yz.alloc(n));
+  HIP_TRY(hipMemcpy(s->fext_yz.p, v.data(), n * sizeof(double), hipMemcpyHostToDevice));
+  s->mesh.fext_yz = s->fext_yz.p;
   return SAA_OK;
 }
 
@@ -383,7 +400,7 @@ int saa_create(const saa_problem *pb, saa_solver **out) {
   s->mesh.mass = s->mass.p;
   s->mesh.fext = s->fext.p;
   s->mesh.tag = s->tag.p;
-  if (refresh_nodal_mass(s, mass) != SAA_OK) {
+  if (refresh_nodal_mass(s, mass) != SAA_OK || refresh_nodal_load(s, fext) != SAA_OK) {
     s->release_all();
     delete s;
     return SAA_E_HIP;
@@ -476,8 +493,10 @@ int saa_set_loads(saa_solver *s, const double *f_ext_host, const double *lumped_
     if (int rc = upload_permuted(s, lumped_mass_host, s->mass.p)) return rc;
     if (int rc = refresh_nodal_mass(s, s->host_tmp)) return rc;
   }
-  if (f_ext_host)
+  if (f_ext_host) {
     if (int rc = upload_permuted(s, f_ext_host, s->fext.p)) return rc;
+    if (int rc = refresh_nodal_load(s, s->host_tmp)) return rc;
+  }
   return SAA_OK;
 }
 

@@ -20,6 +20,8 @@ struct DeviceMesh {
   const double *mass_node;  // (n_nodes) when every node has one mass for its three dofs (the reference's
                             // lumped mass always does), else nullptr: saves 16 B per node and step
   const double *fext;  // (3 n_nodes) un-ramped
+  const double *fext_yz;    // (n_nodes) when the load is (0, v, v) on every node - the reference's body force
+                            // (0,-fz,-fz)*V/4, commons.py:35-41 - else nullptr: saves 16 B per node and step
   const int32_t *tag;  // (n_nodes)
   const int32_t *slot_sidx;  // (n_global_shared) interface slot -> index in the caller's shared list, -1 if foreign
   double lambda_, mu;

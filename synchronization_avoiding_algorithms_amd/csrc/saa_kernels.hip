@@ -313,7 +313,7 @@ __global__ void __launch_bounds__(SAA_LB) fused_step_kernel(DeviceMesh m, const 
     for (int j = 0; j < kPreOwn; ++j) {
       const int i = min(tid + j * nt, n_own3 - 1);
       pm[j] = ABLATE == 4 ? 1.0 : (m.mass_node ? m.mass_node[bd.node_start + i / 3] : m.mass[base + i]);
-      pf[j] = ABLATE == 4 ? 0.0 : m.fext[base + i];
+      pf[j] = ABLATE == 4 ? 0.0 : (m.fext_yz ? (i % 3 == 0 ? 0.0 : m.fext_yz[bd.node_start + i / 3]) : m.fext[base + i]);
       pn[j] = ABLATE == 4 ? 0.0 : dn[base + i];
       ptag[j] = ABLATE == 4 ? 0 : m.tag[bd.node_start + i / 3];
     }
@@ -434,7 +434,8 @@ __global__ void __launch_bounds__(SAA_LB) fused_step_kernel(DeviceMesh m, const 
     if (i < n_own3) finish(i, pm[j], pf[j], pn[j], ptag[j]);
   }
   for (int i = tid + kPreOwn * nt; i < n_own3; i += nt)
-    finish(i, m.mass_node ? m.mass_node[bd.node_start + i / 3] : m.mass[base + i], m.fext[base + i], dn[base + i],
+    finish(i, m.mass_node ? m.mass_node[bd.node_start + i / 3] : m.mass[base + i],
+           m.fext_yz ? (i % 3 == 0 ? 0.0 : m.fext_yz[bd.node_start + i / 3]) : m.fext[base + i], dn[base + i],
            m.tag[bd.node_start + i / 3]);
   if (ABLATE == 8) {  // stamps leave through a buffer of their own (passed in place of the history row)
     T[11] = stamp() - tk;  // update phase

@@ -249,14 +249,15 @@ def test_per_dof_mass_takes_the_general_path():
     rp = ranks[0]
     rng = np.random.default_rng(5)
     lm = rp.l_M * rng.uniform(0.8, 1.25, size=rp.l_M.shape)  # different on x, y, z
-    for masses in (lm, rp.l_M):  # general path, then back to the compact one
-        sol.set_loads(rp.F, masses)
+    f_any = rp.F + rng.uniform(-1e-3, 1e-3, size=rp.F.shape)  # not of the (0, v, v) form
+    for masses, load in ((lm, f_any), (rp.l_M, rp.F)):  # general paths, then back to the compact ones
+        sol.set_loads(load, masses)
         d0 = rng.uniform(-1e-5, 1e-5, size=(sol.n_dof, 1))
         d0[rp.dirichlet] = 0
         sol.set_state(d0, d0, 0.2)
         tn, o0, on = 0.2, d0, d0
         for _ in range(50):
-            o1 = fo.explicit_step(rp.K, rp.F, rp.dirichlet, tn, dt, o0, on, masses, 0.5)
+            o1 = fo.explicit_step(rp.K, load, rp.dirichlet, tn, dt, o0, on, masses, 0.5)
             on, o0, tn = o0, o1, tn + dt
         sol.step(50)
         g0, gn, _ = sol.get_state()
