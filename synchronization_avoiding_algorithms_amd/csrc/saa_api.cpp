@@ -136,7 +136,9 @@ int pick_threads(const saa::Plan &plan, int requested) {
   if (requested > 0) return requested;
   int max_elem = 0;
   for (const auto &b : plan.blocks) max_elem = std::max(max_elem, 2 * b.n_elem);  // items ~ pairs
-  if (max_elem >= 4096) return 1024;
+  // 1024 threads only when the whole grid is one wave of workgroups (one block per CU); several rounds of
+  // 512-thread workgroups overlap better (8.2M tets: 84.6 us/step against 97.9)
+  if (max_elem >= 4096 && plan.blocks.size() <= 256) return 1024;
   if (max_elem >= 2048) return 512;
   if (max_elem >= 512) return 256;
   if (max_elem >= 128) return 128;

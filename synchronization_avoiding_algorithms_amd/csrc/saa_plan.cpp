@@ -61,16 +61,17 @@ int32_t choose_block_count(int32_t n_nodes, int32_t block_nodes) {
   return static_cast<int32_t>(nb);
 }
 
-// Automatic block size.  Up to ~190k nodes (one MI355X-sized partition of ~1M tets) every CU gets exactly
-// ONE block: fewer, larger blocks duplicate fewer border elements (1.25x at 744 owned nodes against
-// 1.37x at 372) and all 256 run as one wave of workgroups of 1024 threads.  Larger partitions use
-// 384-node blocks in several rounds per CU, which overlap each other's memory and LDS phases
-// (measured: 8.2M tets 121 us/step with 377-node blocks against 142 us with 707-node blocks).
+// Automatic block size (measured on MI355X, pair kernel).  Larger blocks duplicate fewer border elements and
+// stage fewer halo records per owned node (element copies 1.25x at ~740 owned nodes against 1.41x at ~380).
+//   * up to ~190k nodes (one MI355X-sized partition of ~1M tets) every CU gets exactly ONE block and all 256
+//     run as a single wave of 1024-thread workgroups (1M tets: 13.0 us/step; 512 blocks of 372: 16.3);
+//   * larger partitions take ~720-node blocks in several rounds of 512-thread workgroups, which overlap each
+//     other's memory and LDS phases (8.2M tets: 84.6 us/step; 377-node blocks 91.5; 942-node blocks 118).
 int32_t auto_block_nodes(int32_t n_nodes) {
   constexpr int32_t kCUs = 256, kBig = 760;
   if (n_nodes <= kDefaultBlockNodes) return n_nodes;  // tiny mesh: one block
   if (n_nodes <= kCUs * kBig) return std::max<int32_t>(96, (n_nodes + kCUs - 1) / kCUs);
-  return kDefaultBlockNodes;
+  return kLargeMeshBlockNodes;
 }
 
 // ------------------------------------------------------------------------------------------------

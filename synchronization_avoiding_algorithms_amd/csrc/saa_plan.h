@@ -60,6 +60,7 @@ struct Plan {
 // local indices and by the LDS budget the kernels are compiled for.
 constexpr int32_t kMaxLocalNodes = 2730;  // 2730 * 48 B = 128 KiB of node records; < 4096 (12-bit item fields)
 constexpr int32_t kDefaultBlockNodes = 384;
+constexpr int32_t kLargeMeshBlockNodes = 720;  // partitions too large for one block per CU
 
 // Builds the plan; on failure returns false and fills err.  block_nodes <= 0 selects the default.
 bool build_plan(int32_t n_nodes, int32_t n_elems, const double *xyz, const int32_t *tets,
