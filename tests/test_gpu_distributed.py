@@ -150,3 +150,55 @@ def test_native_rccl_exchange_single_rank(beam_coarse):
     assert float(iface[24:].abs().max()) == 0.0  # foreign slots re-zeroed
     plain.close()
     synced.close()
+
+
+def _nccl_single_worker(rank, world, port, out_dir):
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    from synchronization_avoiding_algorithms_amd.distributed import PartitionedSolver
+
+    g = np.load(os.path.join(GOLDEN, "beam_coarse_mesh.npz"))
+    epart = np.zeros(len(g["tetra"]), dtype=np.int64)
+    part = PartitionedSolver(g["points"], g["tetra"], g["triangle"], epart, 0, 1, device=0)
+    # the same hand-shake bench.py / PartitionedSolver perform at world > 1: torch's RCCL communicator and the
+    # library's own one (created from the SAME librccl.so) side by side
+    uid = part.solver.comm_unique_id()
+    box = [uid]
+    dist.broadcast_object_list(box, src=0)
+    flag = torch.tensor([1], device="cuda")
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    part.solver.set_interface_buffer(part.iface)
+    part.solver.comm_init(box[0], 0, 1)
+    part.solver.step_synced(50)
+    t = torch.ones(4, device="cuda")
+    dist.all_reduce(t)  # torch's communicator still works afterwards
+    torch.cuda.synchronize()
+    np.save(os.path.join(out_dir, "nccl1.npy"), part.get_state()[0])
+    part.close()
+    dist.destroy_process_group()
+
+
+def test_native_exchange_next_to_torch_nccl(tmp_path):
+    """torch.distributed(nccl) and saa_comm_init use the same librccl.so in one process without disturbing
+    each other (one rank; the multi-rank collective itself needs the driver's multi-GPU node)."""
+    port = 35500 + os.getpid() % 2000
+    mp.spawn(_nccl_single_worker, args=(1, port, str(tmp_path)), nprocs=1, join=True)
+    got = np.load(tmp_path / "nccl1.npy")
+    ref = load_golden("serial_trajectory.npz")
+    # 50 steps lie between the golden snapshots; compare with a fresh plain run instead
+    import synchronization_avoiding_algorithms_amd as saa
+    from synchronization_avoiding_algorithms_amd import fem_setup as fs
+    from synchronization_avoiding_algorithms_amd.mesh import Mesh, clamp_nodes
+
+    g = load_golden("beam_coarse_mesh.npz")
+    mesh = Mesh(g["points"], {"tetra": g["tetra"], "triangle": g["triangle"]})
+    lmd, mu = fs.lame(1e6, 0.3)
+    lay = fs.build_layouts(mesh.tets, np.zeros(len(mesh.tets), dtype=int), 1, len(mesh.points), clamp_nodes(mesh))[0][0]
+    lumped, fpre = fs.lumped_mass_and_load(mesh.points, mesh.tets, 1.0, 0.5)
+    sol = saa.HipExplicitSolver(mesh.points[lay.nodes], lay.cells_local, lumped[lay.local_dof], fpre[lay.local_dof],
+                                lay.dirichlet_dofs, lmd, mu, fs.cfl_dt(mesh.points, mesh.tets, 1e6, 0.3, 1.0, 0.9), 0.5)
+    sol.step(50)
+    assert rel_l2(got, sol.get_state()[0]) < 1e-13 and ref is not None
+    sol.close()
