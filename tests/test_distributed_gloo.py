@@ -117,3 +117,59 @@ def test_two_rank_hybrid_loop_matches_reference(tmp_path):
         assert rel_l2(got["saved"][:, :i_cri + 1], ref[:, :i_cri + 1]) < 1e-13  # synchronised warm-up
         assert rel_l2(got["saved"], ref) < 1e-5        # fp32 LSTM, batched vs batch-1
         assert rel_l2(got["hist"], h[f"r{r}_d_sol_shared"]) < 1e-5
+
+
+def _three_rank_worker(rank, world, port, out_dir, use_gpu):
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if use_gpu:
+        torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from cpu_double import CpuSolverDouble
+    from synchronization_avoiding_algorithms_amd.distributed import PartitionedSolver
+    from synchronization_avoiding_algorithms_amd.mesh import structured_beam
+
+    mesh = structured_beam(3, length=4.0)
+    epart = _t_partition(mesh)
+    kw = {} if use_gpu else dict(tensor_device=torch.device("cpu"), solver_factory=lambda **k: CpuSolverDouble(**k))
+    part = PartitionedSolver(mesh.points, mesh.tets, mesh.triangles, epart, rank, world, **kw)
+    part.step_synced(150)
+    np.savez(os.path.join(out_dir, f"r{rank}.npz"), d=part.get_state()[0][:, 0], nodes=part.layout.nodes,
+             mult=np.array([len(part.global_shared)]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _t_partition(mesh):
+    """Three parts meeting along the line x = 2, y = 0.5: its nodes are held by all three ranks."""
+    c = mesh.points[mesh.tets].mean(axis=1)
+    return np.where(c[:, 0] < 2.0, 0, np.where(c[:, 1] < 0.5, 1, 2)).astype(np.int64)
+
+
+def _check_three_ranks(tmp_path, use_gpu):
+    from oracle import fem_oracle as fo
+    from synchronization_avoiding_algorithms_amd import fem_setup as fs
+    from synchronization_avoiding_algorithms_amd.mesh import clamp_nodes, structured_beam
+
+    port = 37500 + os.getpid() % 2000 + (7 if use_gpu else 0)
+    mp.spawn(_three_rank_worker, args=(3, port, str(tmp_path), use_gpu), nprocs=3, join=True)
+    mesh = structured_beam(3, length=4.0)
+    layouts, gshared = fs.build_layouts(mesh.tets, _t_partition(mesh), 3, len(mesh.points), clamp_nodes(mesh))
+    member = np.zeros(len(mesh.points), dtype=int)
+    for lay in layouts:
+        member[lay.nodes] += 1
+    assert member.max() == 3 and len(gshared) == (member > 1).sum()   # some nodes have three owners
+    ranks, dt, _, _ = fo.setup_problem(mesh.points, mesh.tets, mesh.triangles, 1, np.zeros(len(mesh.tets), dtype=int))
+    serial, _, _, _ = fo.run_ground_truth(ranks, dt, 150)
+    pos = {int(n): i for i, n in enumerate(ranks[0].nodes)}
+    for r in range(3):
+        got = np.load(tmp_path / f"r{r}.npz")
+        idx = np.array([pos[int(n)] for n in got["nodes"]])
+        want = serial[0].reshape(-1, 3)[idx].ravel()
+        assert rel_l2(got["d"], want) < 1e-12, r
+
+
+def test_three_ranks_with_triple_owned_nodes_equal_serial(tmp_path):
+    """Partition invariance through the compact interface buffer when a node has more than two owners."""
+    _check_three_ranks(tmp_path, use_gpu=False)

@@ -202,3 +202,11 @@ def test_native_exchange_next_to_torch_nccl(tmp_path):
     sol.step(50)
     assert rel_l2(got, sol.get_state()[0]) < 1e-13 and ref is not None
     sol.close()
+
+
+def test_three_ranks_on_one_gpu_equal_serial(tmp_path):
+    """Same as the gloo CPU test, with the real kernels (three processes share the test GPU)."""
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from test_distributed_gloo import _check_three_ranks
+
+    _check_three_ranks(tmp_path, use_gpu=True)
