@@ -375,6 +375,36 @@ __global__ void __launch_bounds__(SAA_LB) fused_step_kernel(DeviceMesh m, const 
   }
   lds_barrier();
 
+  // update of one owned dof from its finished force (and publication / prediction for shared nodes)
+  auto finish = [&](int i, double mass, double fpre, double dnv, int32_t tag) {
+    const int n = i / 3, c = i - 3 * n;
+    const double f = acc[n + c * fstride];
+    if (iface != nullptr && (tag & kTagShared)) iface[3 * (int64_t)(tag >> kTagSlotShift) + c] = f;
+    double v = cd_update_dof(f, fpre, mass, rec[6 * n + 3 + c], dnv, k);
+    if (tag & (1 << c)) v = 0.0;  // d1[Local_Dirichlet] = 0   (Dynamic_solver.py:20)
+    if (ABLATE != 8 && table_row != nullptr && (tag & kTagShared)) {
+      // predicted phase: d1[loc_dof_shared] = prediction, recorded as history (Online_predictor.py:298,301)
+      const int64_t j = 3 * (int64_t)m.slot_sidx[tag >> kTagSlotShift] + c;
+      v = table_row[j];
+      if (hist_row != nullptr) hist_row[j] = v;
+    }
+    out[base + i] = v;
+  };
+  // ---- 4b. early update: nodes met by interior items only are complete (the barrier above drained the
+  //          interior atomics); their stores now overlap the boundary items -----------------------------
+  if (!FORCE_ONLY && ABLATE != 4) {
+    const int n_early3 = 3 * bd.n_early;
+#pragma unroll
+    for (int j = 0; j < kPreOwn; ++j) {
+      const int i = tid + j * nt;
+      if (i < n_early3) finish(i, pm[j], pf[j], pn[j], ptag[j]);
+    }
+    for (int i = tid + kPreOwn * nt; i < n_early3; i += nt)
+      finish(i, m.mass_node ? m.mass_node[bd.node_start + i / 3] : m.mass[base + i],
+             m.fext_yz ? (i % 3 == 0 ? 0.0 : m.fext_yz[bd.node_start + i / 3]) : m.fext[base + i], dn[base + i],
+             m.tag[bd.node_start + i / 3]);
+  }
+
   if (ABLATE == 8) {
     const unsigned long long t = stamp();
     T[8] = t - tk;  // halo records to LDS + barrier
@@ -414,26 +444,14 @@ __global__ void __launch_bounds__(SAA_LB) fused_step_kernel(DeviceMesh m, const 
     }
     return;
   }
-  auto finish = [&](int i, double mass, double fpre, double dnv, int32_t tag) {
-    const int n = i / 3, c = i - 3 * n;
-    const double f = acc[n + c * fstride];
-    if (iface != nullptr && (tag & kTagShared)) iface[3 * (int64_t)(tag >> kTagSlotShift) + c] = f;
-    double v = cd_update_dof(f, fpre, mass, rec[6 * n + 3 + c], dnv, k);
-    if (tag & (1 << c)) v = 0.0;  // d1[Local_Dirichlet] = 0   (Dynamic_solver.py:20)
-    if (ABLATE != 8 && table_row != nullptr && (tag & kTagShared)) {
-      // predicted phase: d1[loc_dof_shared] = prediction, recorded as history (Online_predictor.py:298,301)
-      const int64_t j = 3 * (int64_t)m.slot_sidx[tag >> kTagSlotShift] + c;
-      v = table_row[j];
-      if (hist_row != nullptr) hist_row[j] = v;
-    }
-    out[base + i] = v;
-  };
+  const int n_early3 = 3 * bd.n_early;
 #pragma unroll
   for (int j = 0; j < kPreOwn; ++j) {
     const int i = tid + j * nt;
-    if (i < n_own3) finish(i, pm[j], pf[j], pn[j], ptag[j]);
+    if (i >= n_early3 && i < n_own3) finish(i, pm[j], pf[j], pn[j], ptag[j]);
   }
   for (int i = tid + kPreOwn * nt; i < n_own3; i += nt)
+    if (i >= n_early3)
     finish(i, m.mass_node ? m.mass_node[bd.node_start + i / 3] : m.mass[base + i],
            m.fext_yz ? (i % 3 == 0 ? 0.0 : m.fext_yz[bd.node_start + i / 3]) : m.fext[base + i], dn[base + i],
            m.tag[bd.node_start + i / 3]);

@@ -89,7 +89,7 @@ constexpr int kPairSyms[6][5] = {{0, 1, 2, 3, 4}, {0, 2, 3, 1, 4}, {0, 3, 1, 2, 
 
 // Greedy matching of the block's elements into face-sharing pairs with compatible orientation.
 // in: loc = 4 block-local node ids per element.  out: items (8 uint16 each); returns their number.
-int32_t build_items(const std::vector<uint16_t> &loc, int32_t n_elem, std::vector<uint16_t> &items) {
+int32_t build_items(const std::vector<uint16_t> &loc, int32_t n_elem, int32_t n_owned, std::vector<uint16_t> &items) {
   struct Face {
     uint64_t key;
     int32_t elem;
@@ -132,6 +132,12 @@ int32_t build_items(const std::vector<uint16_t> &loc, int32_t n_elem, std::vecto
       if (B[1 + t] == A[1] && B[1 + (t + 1) % 3] == A[3] && B[1 + (t + 2) % 3] == A[2]) return true;
     return false;
   };
+  // an element is interior if all its nodes are owned; pairs never mix the two classes, so that a node met
+  // by interior elements only is complete once the interior items are done (BlockDesc::n_early)
+  auto interior = [&](int32_t e) {
+    const uint16_t *c = &loc[4 * static_cast<size_t>(e)];
+    return c[0] < n_owned && c[1] < n_owned && c[2] < n_owned && c[3] < n_owned;
+  };
   std::vector<char> used(n_elem, 0);
   auto free_degree = [&](int32_t e) {
     int d = 0;
@@ -151,7 +157,7 @@ int32_t build_items(const std::vector<uint16_t> &loc, int32_t n_elem, std::vecto
     uint16_t A[4], B[4];
     for (int k = 0; k < 4; ++k) {
       const int32_t f = nb[4 * static_cast<size_t>(e) + k];
-      if (f < 0 || used[f]) continue;
+      if (f < 0 || used[f] || interior(f) != interior(e)) continue;
       apex_first(e, k, A);
       apex_first(f, nbk[4 * static_cast<size_t>(e) + k], B);
       if (!compatible(A, B)) continue;
@@ -362,6 +368,31 @@ bool build_once(int32_t n_nodes, int32_t n_elems, const double *xyz, const int32
       node_block[i] = b;
     }
 
+  // Within a block, nodes that only meet elements lying entirely inside the block come first ("early"):
+  // their force is complete after the interior items, so their update overlaps the boundary items.
+  std::vector<int32_t> n_early(n_blocks, 0);
+  {
+    std::vector<char> late(n_nodes, 0);  // indexed by internal id
+    for (int32_t e = 0; e < n_elems; ++e) {
+      int32_t g[4];
+      for (int a = 0; a < 4; ++a) g[a] = plan.old_to_new[tets[4 * static_cast<int64_t>(e) + a]];
+      const int32_t b0 = node_block[g[0]];
+      if (node_block[g[1]] != b0 || node_block[g[2]] != b0 || node_block[g[3]] != b0)
+        for (int a = 0; a < 4; ++a) late[g[a]] = 1;
+    }
+    std::vector<int32_t> reordered(n_nodes);
+    for (int32_t b = 0; b < n_blocks; ++b) {
+      int32_t w = block_start[b];
+      for (int32_t i = block_start[b]; i < block_start[b + 1]; ++i)
+        if (!late[i]) reordered[w++] = plan.new_to_old[i];
+      n_early[b] = w - block_start[b];
+      for (int32_t i = block_start[b]; i < block_start[b + 1]; ++i)
+        if (late[i]) reordered[w++] = plan.new_to_old[i];
+    }
+    plan.new_to_old.swap(reordered);
+    for (int32_t i = 0; i < n_nodes; ++i) plan.old_to_new[plan.new_to_old[i]] = i;  // node_block is unchanged
+  }
+
   // element copies per block: an element belongs to every block owning one of its nodes
   std::vector<int64_t> off(n_blocks + 1, 0);
   auto blocks_of = [&](int32_t e, int32_t out[4]) {
@@ -452,7 +483,7 @@ bool build_once(int32_t n_nodes, int32_t n_elems, const double *xyz, const int32
       const BlockDesc &d = plan.blocks[b];
       const int32_t ne = static_cast<int32_t>(off[b + 1] - off[b]);
       loc_b.assign(loc.begin() + 4 * off[b], loc.begin() + 4 * off[b + 1]);
-      const int32_t ni = build_items(loc_b, ne, items);
+      const int32_t ni = build_items(loc_b, ne, d.n_owned, items);
       // interior items (every real vertex owned) first: they can run before the halo records arrive
       std::vector<uint16_t> &out = block_items[b];
       out.resize(8 * static_cast<size_t>(ni));
@@ -497,7 +528,7 @@ bool build_once(int32_t n_nodes, int32_t n_elems, const double *xyz, const int32
     d.elem_off = static_cast<int32_t>(pos);
     d.n_elem = n_items[b];
     d.n_interior = n_interior[b];
-    d.pad_ = 0;
+    d.n_early = n_early[b];
     std::copy(block_items[b].begin(), block_items[b].end(), plan.conn.begin() + 8 * pos);
     pos += n_items[b];
     plan.n_pairs += n_paired[b];
