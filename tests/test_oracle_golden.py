@@ -1,7 +1,6 @@
 """Pin the CPU oracle (oracle/) to vectors produced by the unmodified reference
 (tests/golden/make_golden.py).  CPU only."""
 import numpy as np
-import pytest
 from scipy.sparse import csr_matrix
 
 from conftest import load_golden, rel_l2
