@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""Diagnostic: GPU vs CPU-oracle displacement on beam_coarse over the reference's full run length (1e5 steps)."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+
+from bench import build_rank_solver  # noqa: E402
+from oracle import fem_oracle as fo  # noqa: E402
+from synchronization_avoiding_algorithms_amd.mesh import Mesh  # noqa: E402
+
+g = np.load(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "beam_coarse_mesh.npz"))
+mesh = Mesh(g["points"], {"tetra": g["tetra"], "triangle": g["triangle"]})
+ranks, dt, _, _ = fo.setup_problem(mesh.points, mesh.tets, mesh.triangles, 1, np.zeros(len(mesh.tets), dtype=int))
+sol, lay, _, gdt = build_rank_solver(mesh, 1, 0, 0)
+assert gdt == dt
+steps = (1000, 10000, 30000, 100000)
+_, _, _, snaps = fo.run_ground_truth(ranks, dt, max(steps), snapshots=steps)
+done = 0
+for s in steps:
+    sol.step(s - done)
+    done = s
+    d = sol.get_state()[0]
+    ref = snaps[s][0]
+    print(f"step {s:6d}: rel-L2(GPU vs oracle) = {np.linalg.norm(d - ref) / np.linalg.norm(ref):.3e}   max|d| = {np.abs(ref).max():.4e}")
