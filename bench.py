@@ -237,6 +237,18 @@ def main():
                            "kernel": "fused_step_kernel<false>", "avg_launch_us": 1e3 * ms / k,
                            "algorithmic_bytes_per_launch": b_alg,
                            "algorithmic_bytes_per_element_update": b_alg / ne_total}
+        # HBM traffic per launch from the committed PMC passes of this same command (rocprofv3 --pmc FETCH_SIZE and
+        # --pmc WRITE_SIZE in separate runs; KiB units; FETCH_SIZE doubled: gfx950 counts 64 B per 128-B request,
+        # MI355X_MICROARCH.md "HBM").  Only for the meshes that were profiled; otherwise null.
+        try:
+            with open(os.path.join(REPO, "profiles", "r01_pmc_summary.json")) as fh:
+                pmc = json.load(fh)
+            fetch = pmc[f"q_FETCH_SIZE_{n}:FETCH_SIZE"]["mean_per_dispatch"]
+            write = pmc[f"q_WRITE_SIZE_{n}:WRITE_SIZE"]["mean_per_dispatch"]
+            out["roofline"]["traffic"] = (2.0 * fetch + write) * 1024.0
+            out["roofline"]["traffic_source"] = "profiles/r01_pmc_summary.json (rocprofv3 --pmc, separate passes)"
+        except (OSError, KeyError, ValueError):
+            pass
         copy_bw = measured_copy_bandwidth()
         out["roofline"]["measured_copy_GBps"] = copy_bw / 1e9
         out["roofline"]["frac_of_measured_copy"] = achieved / copy_bw
