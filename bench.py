@@ -118,7 +118,10 @@ def main():
     ap.add_argument("--backend", default="nccl", help="process-group backend for N > 1 (nccl = RCCL)")
     ap.add_argument("--no-sync-avoiding", action="store_true", help="N > 1: skip the sync-avoiding-mode leg")
     ap.add_argument("--torch-exchange", action="store_true",
-                    help="N > 1: all-reduce through torch.distributed instead of RCCL called from C++")
+                    help="N > 1: all-reduce through torch.distributed (same as --exchange torch)")
+    ap.add_argument("--exchange", default="auto", choices=["auto", "peer", "rccl", "torch"],
+                    help="N > 1: how shared-node forces travel: peer = direct xGMI stores (saa_step_peer), rccl = "
+                         "ncclAllReduce from C++, torch = torch.distributed.all_reduce; auto tries them in that order")
     ap.add_argument("--same-device", action="store_true",
                     help="rehearsal on a one-GPU box: every rank uses cuda:0 (needs --backend gloo)")
     args = ap.parse_args()
@@ -149,7 +152,7 @@ def main():
     epart = slab_partition(mesh, world) if world > 1 else np.zeros(ne_total, dtype=np.int64)
     part = PartitionedSolver(mesh.points, mesh.tets, mesh.triangles, epart, rank, world, E=E, nu=NU, rho=RHO,
                              fz=FZ, alpha=ALPHA, gamma=GAMMA, device=local_rank, block_nodes=args.block_nodes,
-                             threads=args.threads, native_exchange=not args.torch_exchange)
+                             threads=args.threads, exchange="torch" if args.torch_exchange else args.exchange)
     sol, gshared, dt = part.solver, part.global_shared, part.dt
 
     def run(k):
@@ -219,9 +222,13 @@ def main():
                                    f"{nn_total} nodes, {world} x-slab partition(s), fp64, E=1e6 nu=0.3 "
                                    f"alpha=0.5 ramped body force, dt={dt:.6e}",
                        "exchange": "none (1 partition)" if world == 1 else
-                                   f"all-reduce of {3 * len(gshared)} fp64 shared-node forces every step, " +
-                                   ("ncclAllReduce issued from C++ (saa_step_synced)" if part.native_exchange
-                                    else f"torch.distributed ({args.backend})"),
+                                   {"peer": f"every step the fp64 forces of the shared nodes ({len(gshared)} in all) are "
+                                            "stored into the neighbour ranks' memory (HIP IPC, xGMI peer stores) and "
+                                            "summed in rank order (saa_step_peer); no collective",
+                                    "rccl": f"all-reduce of {3 * len(gshared)} fp64 shared-node forces every step, "
+                                            "ncclAllReduce issued from C++ (saa_step_synced)",
+                                    "torch": f"all-reduce of {3 * len(gshared)} fp64 shared-node forces every step, "
+                                             f"torch.distributed ({args.backend})"}[part.exchange],
                        "plan": stats},
         }
     if rank == 0 and sync_avoiding is not None:

@@ -3,10 +3,13 @@
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 
+#include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/saa_hip.h"
@@ -114,6 +117,21 @@ struct saa_solver {
   std::vector<double> host_tmp;
   void *comm = nullptr;  // ncclComm_t of the native exchange (saa_comm_init)
   int32_t comm_world = 0;
+  // direct peer exchange (saa_peer_export / saa_peer_attach)
+  void *peer_mem = nullptr;          // this rank's exported allocation: flags + inbox (fine-grained)
+  int32_t peer_world = 0;
+  std::vector<void *> peer_open;     // mapped allocations of the neighbours
+  DevBuf<int32_t> px_src, px_nb_rank, px_err;
+  DevBuf<double *> px_dst;
+  DevBuf<int64_t> px_pstride;
+  DevBuf<unsigned long long *> px_nb_flag;
+  DevBuf<unsigned long long> px_holders;
+  DevBuf<unsigned int> px_counter;
+  DevBuf<double> px_iface, px_test;
+  std::vector<double> px_expected;   // self-test: expected sums
+  saa::PeerMap peer{};
+  bool peer_ready = false;
+  unsigned long long peer_seq = 0;
 
   void rotate() {
     const int old_n = in_;
@@ -127,6 +145,12 @@ struct saa_solver {
     sh_slot.release(); sh_foreign.release(); slot_sidx.release(); conn.release(); xyz.release(); mass.release(); fext.release(); mass_node.release(); fext_yz.release();
     for (auto &b : dbuf) b.release();
     for (auto &b : scratch) b.release();
+    for (void *q : peer_open) (void)hipIpcCloseMemHandle(q);
+    peer_open.clear();
+    if (peer_mem) (void)hipFree(peer_mem);
+    peer_mem = nullptr;
+    px_src.release(); px_nb_rank.release(); px_err.release(); px_dst.release(); px_pstride.release();
+    px_nb_flag.release(); px_holders.release(); px_counter.release(); px_iface.release(); px_test.release();
   }
 };
 
@@ -247,6 +271,18 @@ int refresh_nodal_load(saa_solver *s, const std::vector<double> &f_internal) {
 int ensure_scratch(saa_solver *s, int count) {
   for (int i = 0; i < count; ++i)
     if (!s->scratch[i].p) HIP_TRY(s->scratch[i].alloc(3 * static_cast<size_t>(s->plan.n_nodes)));
+  return SAA_OK;
+}
+
+constexpr size_t kPeerHeaderBytes = 1024;  // flags of up to 64 ranks, then the inbox
+constexpr int kPeerMaxWorld = 64;
+
+// A wait inside the peer-exchange kernel timed out (a neighbour died or never attached).
+int check_peer_error(saa_solver *s) {
+  if (!s->peer_ready) return SAA_OK;
+  int32_t e = 0;
+  HIP_TRY(hipMemcpy(&e, s->px_err.p, sizeof(e), hipMemcpyDeviceToHost));
+  if (e != 0) return fail(SAA_E_STATE, "peer exchange: timed out waiting for a neighbour rank's shared-node forces");
   return SAA_OK;
 }
 
@@ -469,6 +505,8 @@ int saa_set_state(saa_solver *s, const double *d0_host, const double *dn_host, d
 int saa_get_state(saa_solver *s, double *d0_host, double *dn_host, double *tn) {
   if (!s) return fail(SAA_E_ARG, "saa_get_state: null handle");
   HIP_TRY(hipSetDevice(s->device));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  if (int rc = check_peer_error(s)) return rc;
   if (d0_host)
     if (int rc = download_permuted(s, s->dbuf[s->i0].p, d0_host)) return rc;
   if (dn_host)
@@ -626,6 +664,203 @@ int saa_step_synced(saa_solver *s, int32_t nsteps, double *hist_dev, int64_t his
   return check_launch();
 }
 
+int saa_peer_export(saa_solver *s, int32_t world, uint8_t handle_out[64]) {
+  if (!s || !handle_out || world < 2 || world > kPeerMaxWorld)
+    return fail(SAA_E_ARG, "saa_peer_export: bad argument (2 <= world <= 64)");
+  if (s->peer_mem) return fail(SAA_E_STATE, "saa_peer_export: already exported");
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is 64 bytes");
+  HIP_TRY(hipSetDevice(s->device));
+  const size_t bytes = kPeerHeaderBytes + 2 * static_cast<size_t>(world) * 3 * std::max<size_t>(s->n_shared, 1) * sizeof(double);
+  void *mem = nullptr;
+  // fine-grained: stores of other agents become visible while kernels of this one are running
+  HIP_TRY(hipExtMallocWithFlags(&mem, bytes, hipDeviceMallocFinegrained));
+  hipError_t e = hipMemset(mem, 0, bytes);
+  hipIpcMemHandle_t h;
+  if (e == hipSuccess) e = hipIpcGetMemHandle(&h, mem);
+  if (e != hipSuccess) {
+    (void)hipFree(mem);
+    return fail(SAA_E_HIP, std::string("saa_peer_export: ") + hipGetErrorString(e));
+  }
+  std::memcpy(handle_out, &h, 64);
+  s->peer_mem = mem;
+  s->peer_world = world;
+  return SAA_OK;
+}
+
+int saa_peer_attach(saa_solver *s, int32_t rank, int32_t world, const uint8_t *handles, const int32_t *devices,
+                    const int32_t *slot_counts, const int32_t *slots) {
+  if (!s || !handles || !devices || !slot_counts || !slots || world < 2 || rank < 0 || rank >= world)
+    return fail(SAA_E_ARG, "saa_peer_attach: bad argument");
+  if (!s->peer_mem || s->peer_world != world) return fail(SAA_E_STATE, "saa_peer_attach: saa_peer_export(world) first");
+  if (s->peer_ready) return fail(SAA_E_STATE, "saa_peer_attach: already attached");
+  if (s->pending) return fail(SAA_E_STATE, "saa_peer_attach: a synchronised step is in flight");
+  if (slot_counts[rank] != s->n_shared) return fail(SAA_E_ARG, "saa_peer_attach: slot list of this rank has the wrong length");
+  HIP_TRY(hipSetDevice(s->device));
+  // every rank's slot -> position in that rank's shared list
+  std::vector<int64_t> off(world + 1, 0);
+  for (int p = 0; p < world; ++p) {
+    if (slot_counts[p] < 0) return fail(SAA_E_ARG, "saa_peer_attach: negative slot count");
+    off[p + 1] = off[p] + slot_counts[p];
+  }
+  const int32_t ngs = s->n_global_shared;
+  for (int64_t i = 0; i < off[world]; ++i)
+    if (slots[i] < 0 || slots[i] >= ngs) return fail(SAA_E_ARG, "saa_peer_attach: slot out of range");
+  const int32_t *mine = slots + off[rank];
+  std::vector<int32_t> my_sidx(ngs, -1);
+  for (int32_t i = 0; i < s->n_shared; ++i) my_sidx[mine[i]] = i;
+  {
+    std::vector<int32_t> own_slots(s->n_shared);
+    if (s->n_shared > 0)
+      HIP_TRY(hipMemcpy(own_slots.data(), s->sh_slot.p, own_slots.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+    for (int32_t i = 0; i < s->n_shared; ++i)
+      if (mine[i] != own_slots[i])
+        return fail(SAA_E_ARG, "saa_peer_attach: slot list of this rank differs from saa_problem.shared_slots");
+  }
+  std::vector<unsigned long long> holders(std::max<int32_t>(s->n_shared, 1), 0ull);
+  std::vector<int32_t> push_src, nb_rank;
+  std::vector<double *> push_dst;
+  std::vector<int64_t> push_pstride;
+  std::vector<unsigned long long *> nb_flag;
+  s->px_expected.assign(3 * static_cast<size_t>(s->n_shared), 0.0);
+  for (int32_t i = 0; i < s->n_shared; ++i) holders[i] = 1ull << rank;
+  for (int p = 0; p < world; ++p) {
+    if (p == rank) continue;
+    // common slots with rank p, in p's shared order
+    std::vector<std::pair<int32_t, int32_t>> common;  // (my index, p's index)
+    for (int32_t j = 0; j < slot_counts[p]; ++j) {
+      const int32_t mi = my_sidx[slots[off[p] + j]];
+      if (mi >= 0) common.emplace_back(mi, j);
+    }
+    if (common.empty()) continue;
+    hipIpcMemHandle_t h;
+    std::memcpy(&h, handles + 64 * static_cast<size_t>(p), 64);
+    if (devices[p] != s->device) {
+      int can = 0;
+      (void)hipDeviceCanAccessPeer(&can, s->device, devices[p]);
+      if (can) (void)hipDeviceEnablePeerAccess(devices[p], 0);  // "already enabled" is fine; the self-test decides
+      (void)hipGetLastError();
+    }
+    void *base = nullptr;
+    const hipError_t oe = hipIpcOpenMemHandle(&base, h, hipIpcMemLazyEnablePeerAccess);
+    if (oe != hipSuccess || !base) {
+      (void)hipGetLastError();
+      return fail(SAA_E_HIP, "saa_peer_attach: hipIpcOpenMemHandle(rank " + std::to_string(p) + "): " + hipGetErrorString(oe));
+    }
+    s->peer_open.push_back(base);
+    char *cb = static_cast<char *>(base);
+    const int64_t per_sender = 3 * static_cast<int64_t>(std::max<int32_t>(slot_counts[p], 1));
+    double *inbox_p = reinterpret_cast<double *>(cb + kPeerHeaderBytes);
+    nb_rank.push_back(p);
+    nb_flag.push_back(reinterpret_cast<unsigned long long *>(cb) + rank);
+    for (const auto &c : common) {
+      holders[c.first] |= 1ull << p;
+      push_src.push_back(c.first);
+      push_dst.push_back(inbox_p + rank * per_sender + 3 * static_cast<int64_t>(c.second));
+      push_pstride.push_back(per_sender * world);
+    }
+  }
+  for (int32_t i = 0; i < s->n_shared; ++i) {
+    double sum = 0.0;
+    for (int p = 0; p < world; ++p)
+      if ((holders[i] >> p) & 1ull) sum += p + 1;
+    for (int c = 0; c < 3; ++c) s->px_expected[3 * static_cast<size_t>(i) + c] = sum + 0.25 * c;
+  }
+  const int32_t n_push = static_cast<int32_t>(push_src.size()), n_nb = static_cast<int32_t>(nb_rank.size());
+  if (n_nb == 0) {  // no neighbour: keep the device arrays non-null
+    push_src.push_back(0); push_dst.push_back(nullptr); push_pstride.push_back(0);
+    nb_rank.push_back(0); nb_flag.push_back(nullptr);
+  }
+  HIP_TRY(s->px_src.upload(push_src));
+  HIP_TRY(s->px_dst.upload(push_dst));
+  HIP_TRY(s->px_pstride.upload(push_pstride));
+  HIP_TRY(s->px_nb_rank.upload(nb_rank));
+  HIP_TRY(s->px_nb_flag.upload(nb_flag));
+  HIP_TRY(s->px_holders.upload(holders));
+  HIP_TRY(s->px_counter.upload(std::vector<unsigned int>(1, 0u)));
+  HIP_TRY(s->px_err.upload(std::vector<int32_t>(1, 0)));
+  HIP_TRY(s->px_iface.upload(std::vector<double>(3 * static_cast<size_t>(std::max<int32_t>(ngs, 1)), 0.0)));
+  HIP_TRY(s->px_test.upload(std::vector<double>(3 * static_cast<size_t>(std::max<int32_t>(s->n_shared, 1)), 0.0)));
+  saa::PeerMap &pm = s->peer;
+  pm.push_src = s->px_src.p;
+  pm.push_dst = s->px_dst.p;
+  pm.push_pstride = s->px_pstride.p;
+  pm.nb_flag = s->px_nb_flag.p;
+  pm.nb_rank = s->px_nb_rank.p;
+  pm.flags = static_cast<const unsigned long long *>(s->peer_mem);
+  pm.inbox = reinterpret_cast<const double *>(static_cast<char *>(s->peer_mem) + kPeerHeaderBytes);
+  pm.holders = s->px_holders.p;
+  pm.counter = s->px_counter.p;
+  pm.err = s->px_err.p;
+  double timeout_s = 30.0;
+  if (const char *env = std::getenv("SAA_PEER_TIMEOUT_S")) timeout_s = std::max(0.01, std::atof(env));
+  pm.timeout_ticks = static_cast<int64_t>(timeout_s * 1e8);  // wall_clock64(): 100 MHz
+  pm.n_push = n_push;
+  pm.n_nb = n_nb;
+  pm.rank = rank;
+  pm.world = world;
+  s->peer_seq = 0;
+  s->peer_ready = true;
+  return SAA_OK;
+}
+
+int saa_peer_selftest(saa_solver *s, int32_t *ok) {
+  if (!s || !ok) return fail(SAA_E_ARG, "saa_peer_selftest: null argument");
+  *ok = 0;
+  if (!s->peer_ready) return fail(SAA_E_STATE, "saa_peer_selftest: saa_peer_attach first");
+  if (s->pending) return fail(SAA_E_STATE, "saa_peer_selftest: a synchronised step is in flight");
+  HIP_TRY(hipSetDevice(s->device));
+  // every holder contributes rank + 1; the lowest-ranked holder adds 0.25*c so that components differ
+  std::vector<double> own(s->px_iface.n, 0.0);
+  std::vector<unsigned long long> holders(s->px_holders.n);
+  HIP_TRY(hipMemcpy(holders.data(), s->px_holders.p, holders.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  std::vector<int32_t> slot(std::max<int32_t>(s->n_shared, 0));
+  if (s->n_shared > 0)
+    HIP_TRY(hipMemcpy(slot.data(), s->sh_slot.p, slot.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+  for (int32_t i = 0; i < s->n_shared; ++i) {
+    const bool lowest = (holders[i] & ((1ull << s->peer.rank) - 1ull)) == 0ull;
+    for (int c = 0; c < 3; ++c) own[3 * static_cast<size_t>(slot[i]) + c] = s->peer.rank + 1 + (lowest ? 0.25 * c : 0.0);
+  }
+  HIP_TRY(hipMemcpyAsync(s->px_iface.p, own.data(), own.size() * sizeof(double), hipMemcpyHostToDevice, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  ++s->peer_seq;
+  saa::launch_peer_exchange(s->mesh, s->shared, s->peer, s->stream, nullptr, nullptr, nullptr, s->px_iface.p, nullptr,
+                            s->px_test.p, s->consts, s->peer_seq);
+  if (int rc = check_launch()) return rc;
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  int32_t e = 0;
+  HIP_TRY(hipMemcpy(&e, s->px_err.p, sizeof(e), hipMemcpyDeviceToHost));
+  std::vector<double> got(3 * static_cast<size_t>(s->n_shared));
+  if (!got.empty()) HIP_TRY(hipMemcpy(got.data(), s->px_test.p, got.size() * sizeof(double), hipMemcpyDeviceToHost));
+  bool good = e == 0;
+  for (size_t i = 0; i < got.size() && good; ++i) good = got[i] == s->px_expected[i];
+  if (e != 0) {  // leave the error flag clean for a later, agreed fallback decision
+    const int32_t zero = 0;
+    HIP_TRY(hipMemcpy(s->px_err.p, &zero, sizeof(zero), hipMemcpyHostToDevice));
+  }
+  *ok = good ? 1 : 0;
+  return SAA_OK;
+}
+
+int saa_step_peer(saa_solver *s, int32_t nsteps, double *hist_dev, int64_t hist_row0) {
+  if (!s || nsteps < 0 || (hist_dev && hist_row0 < 0)) return fail(SAA_E_ARG, "saa_step_peer: bad argument");
+  if (!s->peer_ready) return fail(SAA_E_STATE, "saa_step_peer: saa_peer_attach has not been called");
+  if (s->pending) return fail(SAA_E_STATE, "saa_step_peer: a synchronised step is in flight");
+  HIP_TRY(hipSetDevice(s->device));
+  const int64_t width = 3 * static_cast<int64_t>(s->n_shared);
+  for (int32_t k = 0; k < nsteps; ++k) {
+    s->set_ramp();
+    saa::launch_fused_step(s->mesh, s->threads, s->lds_bytes, s->stream, s->dbuf[s->i0].p, s->dbuf[s->in_].p,
+                           s->dbuf[s->i1].p, s->px_iface.p, nullptr, nullptr, s->consts);
+    ++s->peer_seq;
+    saa::launch_peer_exchange(s->mesh, s->shared, s->peer, s->stream, s->dbuf[s->i0].p, s->dbuf[s->in_].p,
+                              s->dbuf[s->i1].p, s->px_iface.p, hist_dev ? hist_dev + (hist_row0 + k) * width : nullptr,
+                              nullptr, s->consts, s->peer_seq);
+    s->rotate();
+    s->tn = s->tn + s->consts.dt;
+  }
+  return check_launch();
+}
+
 int saa_step_predicted(saa_solver *s, int32_t nsteps, const double *table_dev, int64_t table_row0,
                        double *hist_dev, int64_t hist_row0) {
   if (!s || nsteps < 0 || table_row0 < 0 || (hist_dev && hist_row0 < 0))
@@ -664,7 +899,7 @@ int saa_synchronize(saa_solver *s) {
   if (!s) return fail(SAA_E_ARG, "saa_synchronize: null handle");
   HIP_TRY(hipSetDevice(s->device));
   HIP_TRY(hipStreamSynchronize(s->stream));
-  return SAA_OK;
+  return check_peer_error(s);
 }
 
 int saa_time_steps(saa_solver *s, int32_t nsteps, double *elapsed_ms) {

@@ -42,7 +42,31 @@ struct SharedMap {
   int32_t n_shared, n_foreign;
 };
 
+// Direct peer exchange of the shared-node forces (saa_peer_attach): every rank owns an "inbox" in fine-grained
+// device memory that its neighbours (ranks holding at least one common shared node) write over xGMI.
+//   inbox layout (doubles): [parity 0|1][sender rank 0..world-1][3 * n_shared of the OWNER, owner's shared order]
+//   flags (uint64)        : flags[sender] = sequence number of the last step whose forces have fully arrived
+struct PeerMap {
+  // sender side: one entry per (neighbour, common shared node)
+  const int32_t *push_src;               // (n_push) index in this rank's shared list
+  double *const *push_dst;               // (n_push) remote address of component 0 in the neighbour's parity-0 inbox
+  const int64_t *push_pstride;           // (n_push) doubles between that neighbour's parity-0 and parity-1 inbox
+  unsigned long long *const *nb_flag;    // (n_nb)   remote address of flags[this rank] in the neighbour's memory
+  const int32_t *nb_rank;                // (n_nb)   neighbour ranks, ascending
+  // receiver side
+  const unsigned long long *flags;       // (world)  this rank's flags
+  const double *inbox;                   // this rank's inbox
+  const unsigned long long *holders;     // (n_shared) bit p set: rank p holds that shared node
+  unsigned int *counter;                 // workgroups of the current launch that have pushed
+  int32_t *err;                          // set to 1 when a wait timed out
+  int64_t timeout_ticks;                 // wall_clock64() ticks (100 MHz) before a wait gives up
+  int32_t n_push, n_nb, rank, world;
+};
+
 hipError_t configure_kernels(int lds_bytes);
+void launch_peer_exchange(const DeviceMesh &m, const SharedMap &sh, const PeerMap &pm, hipStream_t st,
+                          const double *d0, const double *dn, double *d1, const double *iface, double *hist_row,
+                          double *test_out, const StepConsts &k, unsigned long long seq);
 void launch_fused_step(const DeviceMesh &m, int threads, int lds_bytes, hipStream_t st, const double *d0,
                        const double *dn, double *d1, double *iface, const double *table_row, double *hist_row,
                        const StepConsts &k);

@@ -493,6 +493,90 @@ __global__ void iface_finish_kernel(DeviceMesh m, SharedMap sh, const double *__
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Direct peer exchange (replaces the all-reduce of the synchronised step when saa_peer_attach succeeded).
+// One launch per step, after the fused kernel:
+//   1. push   : this rank's partial force of every shared node goes straight into the inbox of every other rank
+//               holding that node (system-scope stores over xGMI); the LAST workgroup to finish its share raises
+//               flags[this rank] = seq in every neighbour's memory (release, system scope),
+//   2. wait   : until every neighbour's flag in this rank's memory has reached seq (bounded: PeerMap::timeout_ticks),
+//   3. finish : shared nodes get the update from the force summed over the holding ranks in RANK ORDER - the order
+//               of syn_cpus (Distributed_tools.py:84-86), identical bits on every rank - (Dynamic_solver.py:26-32).
+// Inboxes are double-buffered by seq parity: a neighbour can be at most one step ahead, because its step seq+1
+// needs this rank's flag seq+1, which is raised only after this rank's finish of step seq.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void store_sys(double *p, double v) {
+  __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v),
+                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ double load_sys(const double *p) {
+  return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(p),
+                                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+}
+
+__global__ void __launch_bounds__(256) peer_exchange_kernel(DeviceMesh m, SharedMap sh, PeerMap pm,
+                                                            const double *__restrict__ d0, const double *__restrict__ dn,
+                                                            double *__restrict__ d1, const double *__restrict__ iface,
+                                                            double *__restrict__ hist_row, double *__restrict__ test_out,
+                                                            StepConsts k, unsigned long long seq) {
+  const int gtid = blockIdx.x * blockDim.x + threadIdx.x, gthreads = gridDim.x * blockDim.x;
+  const int64_t parity = (int64_t)(seq & 1ull);
+  // ---- 1. push ------------------------------------------------------------------------------------
+  for (int i = gtid; i < 3 * pm.n_push; i += gthreads) {
+    const int e = i / 3, c = i - 3 * e;
+    const double v = iface[3 * (int64_t)sh.slot[pm.push_src[e]] + c];
+    store_sys(pm.push_dst[e] + parity * pm.push_pstride[e] + c, v);
+  }
+  __threadfence_system();  // this thread's pushes have reached their destination before the workgroup is counted
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned done = __hip_atomic_fetch_add(pm.counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (done == gridDim.x - 1) {
+      __hip_atomic_store(pm.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // next launch is stream-ordered
+      for (int j = 0; j < pm.n_nb; ++j)
+        __hip_atomic_store(pm.nb_flag[j], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+  // ---- 2. wait for the neighbours' forces of this step -------------------------------------------------
+  for (int j = threadIdx.x; j < pm.n_nb; j += blockDim.x) {
+    const unsigned long long *f = pm.flags + pm.nb_rank[j];
+    const long long t0 = wall_clock64();
+    while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
+      if (wall_clock64() - t0 > pm.timeout_ticks) {  // a neighbour died or never attached: give up, report
+        __hip_atomic_store(pm.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(8);
+    }
+  }
+  __syncthreads();
+  // ---- 3. summed force -> update of the shared nodes -----------------------------------------------------
+  const int64_t per_sender = 3 * (int64_t)sh.n_shared;
+  const double *in = pm.inbox + parity * per_sender * pm.world;
+  for (int i = gtid; i < 3 * sh.n_shared; i += gthreads) {
+    const int s = i / 3, c = i - 3 * s;
+    const unsigned long long held = pm.holders[s];
+    double f = 0.0;
+    bool first = true;
+    for (int p = 0; p < pm.world; ++p) {
+      if (!((held >> p) & 1ull)) continue;
+      const double v = p == pm.rank ? iface[3 * (int64_t)sh.slot[s] + c] : load_sys(in + p * per_sender + i);
+      f = first ? v : f + v;
+      first = false;
+    }
+    if (test_out != nullptr) {  // attach-time self-test: report the sums, leave the state alone
+      test_out[i] = f;
+      continue;
+    }
+    const int node = sh.node[s];
+    const int64_t g = 3 * (int64_t)node + c;
+    double v = cd_update_dof(f, m.fext[g], m.mass[g], d0[g], dn[g], k);
+    if (m.tag[node] & (1 << c)) v = 0.0;
+    d1[g] = v;
+    if (hist_row) hist_row[i] = v;
+  }
+}
+
 // Predicted phase: d1[loc_dof_shared] = table row (Online_predictor.py:298), history record (:301).
 __global__ void halo_overwrite_kernel(SharedMap sh, const double *__restrict__ row, double *__restrict__ d1,
                                       double *__restrict__ hist_row) {
@@ -582,6 +666,16 @@ void launch_iface_finish(const DeviceMesh &m, const SharedMap &sh, hipStream_t s
   if (n == 0) return;
   hipLaunchKernelGGL(iface_finish_kernel, dim3((n + 255) / 256), dim3(256), 0, st, m, sh, d0, dn, d1, iface,
                      hist_row, k);
+}
+
+void launch_peer_exchange(const DeviceMesh &m, const SharedMap &sh, const PeerMap &pm, hipStream_t st,
+                          const double *d0, const double *dn, double *d1, const double *iface, double *hist_row,
+                          double *test_out, const StepConsts &k, unsigned long long seq) {
+  // few, always co-resident workgroups: every one of them waits for the neighbours inside the kernel
+  const int n = 3 * (pm.n_push > sh.n_shared ? pm.n_push : sh.n_shared);
+  const int blocks = n == 0 ? 1 : ((n + 255) / 256 < 64 ? (n + 255) / 256 : 64);
+  hipLaunchKernelGGL(peer_exchange_kernel, dim3(blocks), dim3(256), 0, st, m, sh, pm, d0, dn, d1, iface, hist_row,
+                     test_out, k, seq);
 }
 
 void launch_halo_overwrite(const SharedMap &sh, hipStream_t st, const double *row, double *d1, double *hist_row) {

@@ -38,7 +38,7 @@ class PartitionedSolver:
     def __init__(self, points, cells, facets_or_dirichlet_nodes, epart, rank, world,
                  E=1e6, nu=0.3, rho=1.0, fz=0.5, alpha=0.5, gamma=0.9, device=0, process_group=None,
                  tensor_device=None, solver_factory: Optional[Callable] = None, block_nodes=0, threads=0,
-                 native_exchange=True):
+                 native_exchange=True, exchange="auto"):
         import torch
 
         self.rank, self.world = int(rank), int(world)
@@ -72,9 +72,58 @@ class PartitionedSolver:
             self.solver.set_stream(torch.cuda.current_stream(self.tensor_device).cuda_stream)
         self.input_size = 3 * len(lay.shared_nodes)          # Online_predictor.py:126
         self.steps_done = 0
-        self.native_exchange = False
-        if native_exchange and self.world > 1 and self.tensor_device.type == "cuda":
-            self.native_exchange = self._init_native_exchange()
+        self.device_ordinal = int(device)
+        # how the shared-node forces travel in synchronised steps (all ranks agree on one of them):
+        #   "peer"  direct xGMI peer stores + rank-ordered sums (saa_step_peer), no collective
+        #   "rccl"  ncclAllReduce issued from C++ (saa_step_synced)
+        #   "torch" torch.distributed.all_reduce between saa_step_begin / saa_step_finish
+        if exchange not in ("auto", "peer", "rccl", "torch"):
+            raise ValueError("exchange must be auto, peer, rccl or torch")
+        self.exchange = "torch"
+        if native_exchange and exchange != "torch" and self.world > 1 and self.tensor_device.type == "cuda":
+            if exchange in ("auto", "peer") and self._init_peer_exchange():
+                self.exchange = "peer"
+            elif exchange in ("auto", "rccl") and self._init_native_exchange():
+                self.exchange = "rccl"
+        self.native_exchange = self.exchange == "rccl"
+
+    def _agree(self, ok) -> bool:
+        """True iff every rank reports success (object all-gather: works on nccl and gloo groups)."""
+        import torch.distributed as dist
+
+        box = [None] * self.world
+        dist.all_gather_object(box, int(bool(ok)), group=self.group)
+        return min(box) == 1
+
+    def _init_peer_exchange(self) -> bool:
+        """Map every neighbour's inbox through HIP IPC (``saa_peer_export`` / ``saa_peer_attach``) and prove the
+        path with one exchange of known values; on any failure on any rank all ranks keep the all-reduce."""
+        import torch.distributed as dist
+
+        if not hasattr(self.solver, "peer_export") or self.world > 64:
+            return self._agree(False) and False
+        ok, handle = 1, bytes(64)
+        try:
+            handle = self.solver.peer_export(self.world)
+        except Exception:  # noqa: BLE001
+            ok = 0
+        info = (ok, handle, self.device_ordinal, np.asarray(self.layout.shared_slots, dtype=np.int32))
+        box = [None] * self.world
+        dist.all_gather_object(box, info, group=self.group)
+        if min(b[0] for b in box) == 0:
+            return False
+        try:
+            self.solver.peer_attach(self.rank, self.world, [b[1] for b in box], [b[2] for b in box],
+                                    [b[3] for b in box])
+        except Exception:  # noqa: BLE001
+            ok = 0
+        if not self._agree(ok):  # also the barrier: every inbox is mapped before anybody pushes
+            return False
+        try:
+            ok = int(self.solver.peer_selftest())
+        except Exception:  # noqa: BLE001
+            ok = 0
+        return self._agree(ok)
 
     def _init_native_exchange(self) -> bool:
         """Join an RCCL communicator owned by the C++ side (``saa_comm_init``); on any failure keep the
@@ -114,7 +163,9 @@ class PartitionedSolver:
             self.solver.step(nsteps)
             self.steps_done += nsteps
             return
-        if self.native_exchange:  # fused kernel, ncclAllReduce and finish kernel enqueued from C++
+        if self.exchange == "peer":  # fused kernel + exchange kernel per step, no collective
+            self.solver.step_peer(nsteps, hist, hist_row0)
+        elif self.exchange == "rccl":  # fused kernel, ncclAllReduce and finish kernel enqueued from C++
             self.solver.step_synced(nsteps, hist, hist_row0)
         else:
             for k in range(nsteps):

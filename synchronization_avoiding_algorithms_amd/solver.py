@@ -183,6 +183,34 @@ class HipExplicitSolver:
         """``nsteps`` synchronised steps entirely enqueued from C++ (needs :meth:`comm_init`)."""
         _lib.check(self._lib.saa_step_synced(self._h, int(nsteps), _dev(hist), int(hist_row0)))
 
+    # -- direct peer exchange (xGMI peer stores, no collective) -------------------------------------
+    def peer_export(self, world: int) -> bytes:
+        buf = (C.c_uint8 * 64)()
+        _lib.check(self._lib.saa_peer_export(self._h, int(world), buf))
+        return bytes(buf)
+
+    def peer_attach(self, rank: int, world: int, handles, devices, slot_lists):
+        """``handles``: per-rank 64-byte IPC handles; ``devices``: per-rank HIP ordinals; ``slot_lists``:
+        per-rank ``shared_slots`` arrays (all as all-gathered by the caller)."""
+        hb = (C.c_uint8 * (64 * world)).from_buffer_copy(b"".join(handles))
+        dev = _i32(devices)
+        counts = _i32([len(x) for x in slot_lists])
+        cat = _i32(np.concatenate([np.asarray(x, dtype=np.int32).reshape(-1) for x in slot_lists])
+                   if sum(len(x) for x in slot_lists) else np.zeros(1, dtype=np.int32))
+        _lib.check(self._lib.saa_peer_attach(self._h, int(rank), int(world), hb,
+                                             dev.ctypes.data_as(C.POINTER(C.c_int32)),
+                                             counts.ctypes.data_as(C.POINTER(C.c_int32)),
+                                             cat.ctypes.data_as(C.POINTER(C.c_int32))))
+
+    def peer_selftest(self) -> bool:
+        ok = C.c_int32()
+        _lib.check(self._lib.saa_peer_selftest(self._h, C.byref(ok)))
+        return bool(ok.value)
+
+    def step_peer(self, nsteps=1, hist=None, hist_row0=0):
+        """``nsteps`` synchronised steps through the peer exchange (needs :meth:`peer_attach`)."""
+        _lib.check(self._lib.saa_step_peer(self._h, int(nsteps), _dev(hist), int(hist_row0)))
+
     def step_predicted(self, nsteps, table, table_row0=0, hist=None, hist_row0=0):
         _lib.check(self._lib.saa_step_predicted(self._h, int(nsteps), _dev(table), int(table_row0),
                                                 _dev(hist), int(hist_row0)))

@@ -118,7 +118,7 @@ def test_two_rank_hybrid_loop_matches_reference(tmp_path):
         assert rel_l2(got["hist"], h[f"r{r}_d_sol_shared"]) < 1e-5
 
 
-def _three_rank_worker(rank, world, port, out_dir, use_gpu):
+def _three_rank_worker(rank, world, port, out_dir, use_gpu, exchange="auto"):
     sys.path.insert(0, REPO)
     sys.path.insert(0, os.path.join(REPO, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
@@ -132,7 +132,8 @@ def _three_rank_worker(rank, world, port, out_dir, use_gpu):
     mesh = structured_beam(3, length=4.0)
     epart = _t_partition(mesh)
     kw = {} if use_gpu else dict(tensor_device=torch.device("cpu"), solver_factory=lambda **k: CpuSolverDouble(**k))
-    part = PartitionedSolver(mesh.points, mesh.tets, mesh.triangles, epart, rank, world, **kw)
+    part = PartitionedSolver(mesh.points, mesh.tets, mesh.triangles, epart, rank, world, exchange=exchange, **kw)
+    assert part.exchange == (exchange if use_gpu else "torch"), part.exchange
     part.step_synced(150)
     np.savez(os.path.join(out_dir, f"r{rank}.npz"), d=part.get_state()[0][:, 0], nodes=part.layout.nodes,
              mult=np.array([len(part.global_shared)]))
@@ -146,13 +147,13 @@ def _t_partition(mesh):
     return np.where(c[:, 0] < 2.0, 0, np.where(c[:, 1] < 0.5, 1, 2)).astype(np.int64)
 
 
-def _check_three_ranks(tmp_path, use_gpu):
+def _check_three_ranks(tmp_path, use_gpu, exchange="auto"):
     from oracle import fem_oracle as fo
     from synchronization_avoiding_algorithms_amd import fem_setup as fs
     from synchronization_avoiding_algorithms_amd.mesh import clamp_nodes, structured_beam
 
-    port = 37500 + os.getpid() % 2000 + (7 if use_gpu else 0)
-    mp.spawn(_three_rank_worker, args=(3, port, str(tmp_path), use_gpu), nprocs=3, join=True)
+    port = 37500 + os.getpid() % 2000 + (7 if use_gpu else 0) + (13 if exchange == "peer" else 0)
+    mp.spawn(_three_rank_worker, args=(3, port, str(tmp_path), use_gpu, exchange), nprocs=3, join=True)
     mesh = structured_beam(3, length=4.0)
     layouts, gshared = fs.build_layouts(mesh.tets, _t_partition(mesh), 3, len(mesh.points), clamp_nodes(mesh))
     member = np.zeros(len(mesh.points), dtype=int)

@@ -15,7 +15,7 @@ from conftest import GOLDEN, REPO, load_golden, rel_l2
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, steps, out_dir):
+def _worker(rank, world, port, steps, out_dir, exchange):
     sys.path.insert(0, REPO)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     torch.cuda.set_device(0)
@@ -24,7 +24,9 @@ def _worker(rank, world, port, steps, out_dir):
 
     g = np.load(os.path.join(GOLDEN, "beam_coarse_mesh.npz"))
     t = np.load(os.path.join(GOLDEN, "tworank_trajectory.npz"))
-    part = PartitionedSolver(g["points"], g["tetra"], g["triangle"], t["epart"], rank, world, device=0)
+    part = PartitionedSolver(g["points"], g["tetra"], g["triangle"], t["epart"], rank, world, device=0,
+                             exchange=exchange)
+    assert part.exchange == exchange, part.exchange  # no silent fallback in the test
     hist = torch.zeros((max(steps), part.input_size), dtype=torch.float64, device="cuda")
     snaps, done = {}, 0
     for s in steps:
@@ -47,10 +49,13 @@ def _worker(rank, world, port, steps, out_dir):
     dist.destroy_process_group()
 
 
-def test_two_ranks_on_one_gpu_match_reference(tmp_path):
+@pytest.mark.parametrize("exchange", ["peer", "torch"])
+def test_two_ranks_on_one_gpu_match_reference(tmp_path, exchange):
+    """``peer``: shared-node forces stored straight into the other rank's inbox through HIP IPC (the path the
+    multi-GPU bench takes over xGMI); ``torch``: begin / all_reduce / finish."""
     steps = (1, 10, 100, 1000, 5000)
-    port = 29500 + os.getpid() % 2000
-    mp.spawn(_worker, args=(2, port, steps, str(tmp_path)), nprocs=2, join=True)
+    port = 29500 + os.getpid() % 2000 + (11 if exchange == "peer" else 0)
+    mp.spawn(_worker, args=(2, port, steps, str(tmp_path), exchange), nprocs=2, join=True)
     t = load_golden("tworank_trajectory.npz")
     bound = {1: 1e-15, 10: 1e-14, 100: 1e-13, 1000: 5e-12, 5000: 5e-11}
     for r in range(2):
@@ -204,9 +209,46 @@ def test_native_exchange_next_to_torch_nccl(tmp_path):
     sol.close()
 
 
-def test_three_ranks_on_one_gpu_equal_serial(tmp_path):
-    """Same as the gloo CPU test, with the real kernels (three processes share the test GPU)."""
+@pytest.mark.parametrize("exchange", ["peer", "torch"])
+def test_three_ranks_on_one_gpu_equal_serial(tmp_path, exchange):
+    """Same as the gloo CPU test, with the real kernels (three processes share the test GPU); with ``peer`` the
+    triple-owned nodes receive two pushes each and are summed in rank order."""
     sys.path.insert(0, os.path.join(REPO, "tests"))
     from test_distributed_gloo import _check_three_ranks
 
-    _check_three_ranks(tmp_path, use_gpu=True)
+    _check_three_ranks(tmp_path, use_gpu=True, exchange=exchange)
+
+
+def _dead_peer_worker(rank, world, port, out_dir):
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0",
+                      SAA_PEER_TIMEOUT_S="0.3")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from synchronization_avoiding_algorithms_amd.distributed import PartitionedSolver
+
+    g = np.load(os.path.join(GOLDEN, "beam_coarse_mesh.npz"))
+    t = np.load(os.path.join(GOLDEN, "tworank_trajectory.npz"))
+    part = PartitionedSolver(g["points"], g["tetra"], g["triangle"], t["epart"], rank, world, device=0, exchange="peer")
+    assert part.exchange == "peer"
+    part.step_synced(3)
+    part.get_state()
+    dist.barrier()
+    outcome = "idle"
+    if rank == 0:  # rank 1 never takes this step: the wait inside the exchange kernel must give up, not hang
+        part.step_synced(1)
+        try:
+            part.get_state()
+            outcome = "no error"
+        except RuntimeError as e:
+            outcome = str(e)
+    dist.barrier()
+    with open(os.path.join(out_dir, f"dead{rank}.txt"), "w") as fh:
+        fh.write(outcome)
+    dist.destroy_process_group()
+
+
+def test_peer_exchange_times_out_instead_of_hanging(tmp_path):
+    port = 39500 + os.getpid() % 2000
+    mp.spawn(_dead_peer_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert "timed out waiting for a neighbour" in (tmp_path / "dead0.txt").read_text()
