@@ -146,26 +146,28 @@ int saa_comm_unique_id(const char *rccl_path, uint8_t id_out[128]);
 int saa_comm_init(saa_solver *s, const char *rccl_path, const uint8_t id[128], int32_t rank, int32_t world);
 int saa_step_synced(saa_solver *s, int32_t nsteps, double *hist_dev, int64_t hist_row0);
 
-/* Direct peer exchange: the synchronised step without a collective.  The partial force of every shared node is
- * stored straight into the memory of the other ranks holding that node (fine-grained device memory mapped through
- * HIP IPC, xGMI peer stores) and every rank sums what it received in RANK ORDER - the summation order of syn_cpus
- * (Distributed_tools.py:84-86), so all ranks obtain identical bits.  Only ranks with a common shared node talk to
- * each other; a step costs two enqueues (fused kernel + exchange kernel) and one xGMI store latency.
- *   saa_peer_export   : allocates this rank's inbox (2 x world x 3*n_shared doubles + flags) and returns its
- *                       64-byte hipIpcMemHandle_t; the caller all-gathers handles, device ordinals and the
- *                       shared_slots lists of every rank (any transport: torch.distributed, MPI, files)
- *   saa_peer_attach   : maps the inboxes of the neighbours (ranks with a common slot) and builds the push lists;
- *                       handles = world x 64 bytes, devices[world], slot_counts[world], slots = the ranks'
- *                       shared_slots lists concatenated in rank order (this rank's must equal saa_problem's)
+/* Direct peer exchange: the synchronised step without a collective and without a second kernel.  Inside the fused
+ * step kernel the partial force of every shared node is stored straight into the memory of the other ranks holding
+ * that node (fine-grained device memory mapped through HIP IPC; xGMI peer stores; every 16-byte entry carries the
+ * step's sequence number, so it is its own "ready" flag) and every rank sums what it received in RANK ORDER - the
+ * summation order of syn_cpus (Distributed_tools.py:84-86), so all ranks obtain identical bits.  Only ranks with a
+ * common shared node talk to each other; the xGMI flight time hides under the update of the non-shared nodes.
+ *   saa_peer_export   : allocates this rank's inbox and returns its 64-byte hipIpcMemHandle_t plus, per shared
+ *                       node, its position in this rank's push order (order_out, n_shared values); the caller
+ *                       all-gathers handles, device ordinals, shared_slots lists and push orders of every rank
+ *                       (any transport: torch.distributed, MPI, files)
+ *   saa_peer_attach   : maps the inboxes of the neighbours (ranks with a common slot) and builds the push / receive
+ *                       lists; handles = world x 64 bytes, devices[world], slot_counts[world], slots / orders = the
+ *                       ranks' lists concatenated in rank order (this rank's slots must equal saa_problem's)
  *   saa_peer_selftest : COLLECTIVE over the attached ranks: one exchange of known values; *ok = 1 iff every
  *                       sum arrived intact within the time limit.  The caller agrees on min(ok) over ranks
  *                       before relying on saa_step_peer, and otherwise keeps the all-reduce path
- *   saa_step_peer     : nsteps synchronised steps; history rows as in saa_step_finish
- * Waits inside the exchange kernel are bounded (30 s, env SAA_PEER_TIMEOUT_S): a dead neighbour turns into
- * SAA_E_STATE at the next saa_synchronize / saa_get_state instead of a hang. */
-int saa_peer_export(saa_solver *s, int32_t world, uint8_t handle_out[64]);
+ *   saa_step_peer     : nsteps synchronised steps, ONE kernel launch each; history rows as in saa_step_finish
+ * Waits inside the kernel are bounded (30 s, env SAA_PEER_TIMEOUT_S): a dead neighbour turns into SAA_E_STATE at
+ * the next saa_synchronize / saa_get_state instead of a hang. */
+int saa_peer_export(saa_solver *s, int32_t world, uint8_t handle_out[64], int32_t *order_out);
 int saa_peer_attach(saa_solver *s, int32_t rank, int32_t world, const uint8_t *handles, const int32_t *devices,
-                    const int32_t *slot_counts, const int32_t *slots);
+                    const int32_t *slot_counts, const int32_t *slots, const int32_t *orders);
 int saa_peer_selftest(saa_solver *s, int32_t *ok);
 int saa_step_peer(saa_solver *s, int32_t nsteps, double *hist_dev, int64_t hist_row0);
 

@@ -121,17 +121,15 @@ struct saa_solver {
   void *peer_mem = nullptr;          // this rank's exported allocation: flags + inbox (fine-grained)
   int32_t peer_world = 0;
   std::vector<void *> peer_open;     // mapped allocations of the neighbours
-  DevBuf<int32_t> px_src, px_nb_rank, px_err;
-  DevBuf<double *> px_dst;
-  DevBuf<int64_t> px_pstride;
-  DevBuf<unsigned long long *> px_nb_flag;
+  DevBuf<int32_t> px_blk_off, px_node, px_sidx, px_nb_off, px_err;
+  DevBuf<saa::PeerEntry *> px_dst;
+  DevBuf<int64_t> px_pstride, px_recv;
   DevBuf<unsigned long long> px_holders;
-  DevBuf<unsigned int> px_counter;
-  DevBuf<double> px_iface, px_test;
+  DevBuf<double> px_own, px_test;
   std::vector<double> px_expected;   // self-test: expected sums
   saa::PeerMap peer{};
   bool peer_ready = false;
-  unsigned long long peer_seq = 0;
+  unsigned peer_seq = 0;
 
   void rotate() {
     const int old_n = in_;
@@ -149,8 +147,8 @@ struct saa_solver {
     peer_open.clear();
     if (peer_mem) (void)hipFree(peer_mem);
     peer_mem = nullptr;
-    px_src.release(); px_nb_rank.release(); px_err.release(); px_dst.release(); px_pstride.release();
-    px_nb_flag.release(); px_holders.release(); px_counter.release(); px_iface.release(); px_test.release();
+    px_blk_off.release(); px_node.release(); px_sidx.release(); px_nb_off.release(); px_err.release();
+    px_dst.release(); px_pstride.release(); px_recv.release(); px_holders.release(); px_own.release(); px_test.release();
   }
 };
 
@@ -274,8 +272,7 @@ int ensure_scratch(saa_solver *s, int count) {
   return SAA_OK;
 }
 
-constexpr size_t kPeerHeaderBytes = 1024;  // flags of up to 64 ranks, then the inbox
-constexpr int kPeerMaxWorld = 64;
+constexpr int kPeerMaxWorld = 64;  // holder masks are 64 bits
 
 // A wait inside the peer-exchange kernel timed out (a neighbour died or never attached).
 int check_peer_error(saa_solver *s) {
@@ -664,22 +661,35 @@ int saa_step_synced(saa_solver *s, int32_t nsteps, double *hist_dev, int64_t his
   return check_launch();
 }
 
-int saa_peer_export(saa_solver *s, int32_t world, uint8_t handle_out[64]) {
-  if (!s || !handle_out || world < 2 || world > kPeerMaxWorld)
+int saa_peer_export(saa_solver *s, int32_t world, uint8_t handle_out[64], int32_t *order_out) {
+  if (!s || !handle_out || (s->n_shared > 0 && !order_out) || world < 2 || world > kPeerMaxWorld)
     return fail(SAA_E_ARG, "saa_peer_export: bad argument (2 <= world <= 64)");
   if (s->peer_mem) return fail(SAA_E_STATE, "saa_peer_export: already exported");
   static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is 64 bytes");
   HIP_TRY(hipSetDevice(s->device));
-  const size_t bytes = kPeerHeaderBytes + 2 * static_cast<size_t>(world) * 3 * std::max<size_t>(s->n_shared, 1) * sizeof(double);
+  const size_t bytes = 2 * static_cast<size_t>(world) * 3 * std::max<size_t>(s->n_shared, 1) * sizeof(saa::PeerEntry);
   void *mem = nullptr;
   // fine-grained: stores of other agents become visible while kernels of this one are running
   HIP_TRY(hipExtMallocWithFlags(&mem, bytes, hipDeviceMallocFinegrained));
-  hipError_t e = hipMemset(mem, 0, bytes);
+  hipError_t e = hipMemset(mem, 0, bytes);  // sequence number 0 is never sent
   hipIpcMemHandle_t h;
   if (e == hipSuccess) e = hipIpcGetMemHandle(&h, mem);
   if (e != hipSuccess) {
     (void)hipFree(mem);
     return fail(SAA_E_HIP, std::string("saa_peer_export: ") + hipGetErrorString(e));
+  }
+  // push order of this rank: position of every shared node in internal-node order
+  {
+    std::vector<int32_t> nodes(s->n_shared), idx(s->n_shared);
+    if (s->n_shared > 0)
+      e = hipMemcpy(nodes.data(), s->sh_node.p, nodes.size() * sizeof(int32_t), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) {
+      (void)hipFree(mem);
+      return fail(SAA_E_HIP, std::string("saa_peer_export: ") + hipGetErrorString(e));
+    }
+    for (int32_t i = 0; i < s->n_shared; ++i) idx[i] = i;
+    std::sort(idx.begin(), idx.end(), [&](int32_t a, int32_t b) { return nodes[a] < nodes[b]; });
+    for (int32_t q = 0; q < s->n_shared; ++q) order_out[idx[q]] = q;
   }
   std::memcpy(handle_out, &h, 64);
   s->peer_mem = mem;
@@ -688,48 +698,72 @@ int saa_peer_export(saa_solver *s, int32_t world, uint8_t handle_out[64]) {
 }
 
 int saa_peer_attach(saa_solver *s, int32_t rank, int32_t world, const uint8_t *handles, const int32_t *devices,
-                    const int32_t *slot_counts, const int32_t *slots) {
-  if (!s || !handles || !devices || !slot_counts || !slots || world < 2 || rank < 0 || rank >= world)
+                    const int32_t *slot_counts, const int32_t *slots, const int32_t *orders) {
+  if (!s || !handles || !devices || !slot_counts || !slots || !orders || world < 2 || rank < 0 || rank >= world)
     return fail(SAA_E_ARG, "saa_peer_attach: bad argument");
   if (!s->peer_mem || s->peer_world != world) return fail(SAA_E_STATE, "saa_peer_attach: saa_peer_export(world) first");
   if (s->peer_ready) return fail(SAA_E_STATE, "saa_peer_attach: already attached");
   if (s->pending) return fail(SAA_E_STATE, "saa_peer_attach: a synchronised step is in flight");
   if (slot_counts[rank] != s->n_shared) return fail(SAA_E_ARG, "saa_peer_attach: slot list of this rank has the wrong length");
   HIP_TRY(hipSetDevice(s->device));
-  // every rank's slot -> position in that rank's shared list
   std::vector<int64_t> off(world + 1, 0);
   for (int p = 0; p < world; ++p) {
     if (slot_counts[p] < 0) return fail(SAA_E_ARG, "saa_peer_attach: negative slot count");
     off[p + 1] = off[p] + slot_counts[p];
   }
-  const int32_t ngs = s->n_global_shared;
+  const int32_t ngs = s->n_global_shared, nsh = s->n_shared;
   for (int64_t i = 0; i < off[world]; ++i)
     if (slots[i] < 0 || slots[i] >= ngs) return fail(SAA_E_ARG, "saa_peer_attach: slot out of range");
   const int32_t *mine = slots + off[rank];
-  std::vector<int32_t> my_sidx(ngs, -1);
-  for (int32_t i = 0; i < s->n_shared; ++i) my_sidx[mine[i]] = i;
-  {
-    std::vector<int32_t> own_slots(s->n_shared);
-    if (s->n_shared > 0)
-      HIP_TRY(hipMemcpy(own_slots.data(), s->sh_slot.p, own_slots.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
-    for (int32_t i = 0; i < s->n_shared; ++i)
-      if (mine[i] != own_slots[i])
-        return fail(SAA_E_ARG, "saa_peer_attach: slot list of this rank differs from saa_problem.shared_slots");
+  std::vector<int32_t> own_slots(nsh), own_nodes(nsh);
+  if (nsh > 0) {
+    HIP_TRY(hipMemcpy(own_slots.data(), s->sh_slot.p, nsh * sizeof(int32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(own_nodes.data(), s->sh_node.p, nsh * sizeof(int32_t), hipMemcpyDeviceToHost));
   }
-  std::vector<unsigned long long> holders(std::max<int32_t>(s->n_shared, 1), 0ull);
-  std::vector<int32_t> push_src, nb_rank;
-  std::vector<double *> push_dst;
-  std::vector<int64_t> push_pstride;
-  std::vector<unsigned long long *> nb_flag;
-  s->px_expected.assign(3 * static_cast<size_t>(s->n_shared), 0.0);
-  for (int32_t i = 0; i < s->n_shared; ++i) holders[i] = 1ull << rank;
-  for (int p = 0; p < world; ++p) {
+  for (int32_t i = 0; i < nsh; ++i)
+    if (mine[i] != own_slots[i])
+      return fail(SAA_E_ARG, "saa_peer_attach: slot list of this rank differs from saa_problem.shared_slots");
+  // this rank's shared nodes sorted by internal node id: the nodes of one plan block are one range
+  std::vector<int32_t> order(nsh);
+  for (int32_t i = 0; i < nsh; ++i) order[i] = i;
+  std::sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return own_nodes[a] < own_nodes[b]; });
+  std::vector<int32_t> q_of_sidx(std::max<int32_t>(nsh, 1), 0), node(std::max<int32_t>(nsh, 1), 0), sidx(std::max<int32_t>(nsh, 1), 0);
+  for (int32_t q = 0; q < nsh; ++q) {
+    node[q] = own_nodes[order[q]];
+    sidx[q] = order[q];
+    q_of_sidx[order[q]] = q;
+  }
+  std::vector<int32_t> blk_off(s->plan.blocks.size() + 1, 0);
+  {
+    int32_t q = 0;
+    for (size_t b = 0; b < s->plan.blocks.size(); ++b) {
+      blk_off[b] = q;
+      const int32_t end = s->plan.blocks[b].node_start + s->plan.blocks[b].n_owned;
+      while (q < nsh && node[q] < end) ++q;
+    }
+    blk_off[s->plan.blocks.size()] = q;
+    if (q != nsh) return fail(SAA_E_STATE, "saa_peer_attach: shared node outside every block");
+  }
+  std::vector<int32_t> slot_q(ngs, -1);  // interface slot -> q on this rank
+  for (int32_t i = 0; i < nsh; ++i) slot_q[own_slots[i]] = q_of_sidx[i];
+  std::vector<unsigned long long> holders(std::max<int32_t>(nsh, 1), 0ull);
+  for (int32_t q = 0; q < nsh; ++q) holders[q] = 1ull << rank;
+  struct Nb {
+    int32_t p;
+    saa::PeerEntry *dst;
+    int64_t pstride, recv;
+  };
+  std::vector<std::vector<Nb>> nbs(std::max<int32_t>(nsh, 1));
+  const int64_t per_me = 3 * static_cast<int64_t>(std::max<int32_t>(nsh, 1));
+  for (int p = 0; p < world; ++p) {  // ascending: the neighbour entries of a node end up in rank order
     if (p == rank) continue;
-    // common slots with rank p, in p's shared order
-    std::vector<std::pair<int32_t, int32_t>> common;  // (my index, p's index)
+    struct Common {
+      int32_t q, order_p;
+    };
+    std::vector<Common> common;
     for (int32_t j = 0; j < slot_counts[p]; ++j) {
-      const int32_t mi = my_sidx[slots[off[p] + j]];
-      if (mi >= 0) common.emplace_back(mi, j);
+      const int32_t q = slot_q[slots[off[p] + j]];
+      if (q >= 0) common.push_back({q, orders[off[p] + j]});
     }
     if (common.empty()) continue;
     hipIpcMemHandle_t h;
@@ -747,57 +781,81 @@ int saa_peer_attach(saa_solver *s, int32_t rank, int32_t world, const uint8_t *h
       return fail(SAA_E_HIP, "saa_peer_attach: hipIpcOpenMemHandle(rank " + std::to_string(p) + "): " + hipGetErrorString(oe));
     }
     s->peer_open.push_back(base);
-    char *cb = static_cast<char *>(base);
-    const int64_t per_sender = 3 * static_cast<int64_t>(std::max<int32_t>(slot_counts[p], 1));
-    double *inbox_p = reinterpret_cast<double *>(cb + kPeerHeaderBytes);
-    nb_rank.push_back(p);
-    nb_flag.push_back(reinterpret_cast<unsigned long long *>(cb) + rank);
-    for (const auto &c : common) {
-      holders[c.first] |= 1ull << p;
-      push_src.push_back(c.first);
-      push_dst.push_back(inbox_p + rank * per_sender + 3 * static_cast<int64_t>(c.second));
-      push_pstride.push_back(per_sender * world);
+    const int64_t per_p = 3 * static_cast<int64_t>(std::max<int32_t>(slot_counts[p], 1));
+    saa::PeerEntry *inbox_p = static_cast<saa::PeerEntry *>(base);
+    // position of every common node in MY push order (what I write) and in p's push order (what I read)
+    std::vector<int32_t> t_send(common.size()), t_recv(common.size()), by(common.size());
+    for (size_t i = 0; i < common.size(); ++i) by[i] = static_cast<int32_t>(i);
+    std::sort(by.begin(), by.end(), [&](int32_t a, int32_t b) { return common[a].q < common[b].q; });
+    for (size_t t = 0; t < by.size(); ++t) t_send[by[t]] = static_cast<int32_t>(t);
+    std::sort(by.begin(), by.end(), [&](int32_t a, int32_t b) { return common[a].order_p < common[b].order_p; });
+    for (size_t t = 0; t < by.size(); ++t) t_recv[by[t]] = static_cast<int32_t>(t);
+    for (size_t i = 0; i < common.size(); ++i) {
+      holders[common[i].q] |= 1ull << p;
+      nbs[common[i].q].push_back({p, inbox_p + rank * per_p + 3 * static_cast<int64_t>(t_send[i]), per_p * world,
+                                  p * per_me + 3 * static_cast<int64_t>(t_recv[i])});
     }
   }
-  for (int32_t i = 0; i < s->n_shared; ++i) {
+  std::vector<int32_t> nb_off(nsh + 1, 0);
+  std::vector<saa::PeerEntry *> push_dst;
+  std::vector<int64_t> push_pstride, recv_idx;
+  for (int32_t q = 0; q < nsh; ++q) {
+    nb_off[q] = static_cast<int32_t>(push_dst.size());
+    for (const Nb &e : nbs[q]) {
+      push_dst.push_back(e.dst);
+      push_pstride.push_back(e.pstride);
+      recv_idx.push_back(e.recv);
+    }
+  }
+  nb_off[nsh] = static_cast<int32_t>(push_dst.size());
+  if (push_dst.empty()) {  // keep the device arrays non-null
+    push_dst.push_back(nullptr);
+    push_pstride.push_back(0);
+    recv_idx.push_back(0);
+  }
+  // self-test payload (node-sorted order) and its expected sums (caller's shared order): every holder contributes
+  // rank + 1, the lowest-ranked holder adds 0.25*c so that the components differ
+  std::vector<double> own(3 * static_cast<size_t>(std::max<int32_t>(nsh, 1)), 0.0);
+  s->px_expected.assign(3 * static_cast<size_t>(nsh), 0.0);
+  for (int32_t q = 0; q < nsh; ++q) {
     double sum = 0.0;
     for (int p = 0; p < world; ++p)
-      if ((holders[i] >> p) & 1ull) sum += p + 1;
-    for (int c = 0; c < 3; ++c) s->px_expected[3 * static_cast<size_t>(i) + c] = sum + 0.25 * c;
+      if ((holders[q] >> p) & 1ull) sum += p + 1;
+    const bool lowest = (holders[q] & ((1ull << rank) - 1ull)) == 0ull;
+    for (int c = 0; c < 3; ++c) {
+      own[3 * static_cast<size_t>(q) + c] = rank + 1 + (lowest ? 0.25 * c : 0.0);
+      s->px_expected[3 * static_cast<size_t>(sidx[q]) + c] = sum + 0.25 * c;
+    }
   }
-  const int32_t n_push = static_cast<int32_t>(push_src.size()), n_nb = static_cast<int32_t>(nb_rank.size());
-  if (n_nb == 0) {  // no neighbour: keep the device arrays non-null
-    push_src.push_back(0); push_dst.push_back(nullptr); push_pstride.push_back(0);
-    nb_rank.push_back(0); nb_flag.push_back(nullptr);
-  }
-  HIP_TRY(s->px_src.upload(push_src));
+  HIP_TRY(s->px_blk_off.upload(blk_off));
+  HIP_TRY(s->px_node.upload(node));
+  HIP_TRY(s->px_sidx.upload(sidx));
+  HIP_TRY(s->px_nb_off.upload(nb_off));
   HIP_TRY(s->px_dst.upload(push_dst));
   HIP_TRY(s->px_pstride.upload(push_pstride));
-  HIP_TRY(s->px_nb_rank.upload(nb_rank));
-  HIP_TRY(s->px_nb_flag.upload(nb_flag));
+  HIP_TRY(s->px_recv.upload(recv_idx));
   HIP_TRY(s->px_holders.upload(holders));
-  HIP_TRY(s->px_counter.upload(std::vector<unsigned int>(1, 0u)));
   HIP_TRY(s->px_err.upload(std::vector<int32_t>(1, 0)));
-  HIP_TRY(s->px_iface.upload(std::vector<double>(3 * static_cast<size_t>(std::max<int32_t>(ngs, 1)), 0.0)));
-  HIP_TRY(s->px_test.upload(std::vector<double>(3 * static_cast<size_t>(std::max<int32_t>(s->n_shared, 1)), 0.0)));
+  HIP_TRY(s->px_own.upload(own));
+  HIP_TRY(s->px_test.upload(std::vector<double>(own.size(), 0.0)));
   saa::PeerMap &pm = s->peer;
-  pm.push_src = s->px_src.p;
+  pm.blk_off = s->px_blk_off.p;
+  pm.node = s->px_node.p;
+  pm.sidx = s->px_sidx.p;
+  pm.holders = s->px_holders.p;
+  pm.nb_off = s->px_nb_off.p;
   pm.push_dst = s->px_dst.p;
   pm.push_pstride = s->px_pstride.p;
-  pm.nb_flag = s->px_nb_flag.p;
-  pm.nb_rank = s->px_nb_rank.p;
-  pm.flags = static_cast<const unsigned long long *>(s->peer_mem);
-  pm.inbox = reinterpret_cast<const double *>(static_cast<char *>(s->peer_mem) + kPeerHeaderBytes);
-  pm.holders = s->px_holders.p;
-  pm.counter = s->px_counter.p;
+  pm.recv_idx = s->px_recv.p;
+  pm.inbox = static_cast<const saa::PeerEntry *>(s->peer_mem);
+  pm.parity_stride = per_me * world;
   pm.err = s->px_err.p;
   double timeout_s = 30.0;
   if (const char *env = std::getenv("SAA_PEER_TIMEOUT_S")) timeout_s = std::max(0.01, std::atof(env));
   pm.timeout_ticks = static_cast<int64_t>(timeout_s * 1e8);  // wall_clock64(): 100 MHz
-  pm.n_push = n_push;
-  pm.n_nb = n_nb;
   pm.rank = rank;
   pm.world = world;
+  pm.n_shared = nsh;
   s->peer_seq = 0;
   s->peer_ready = true;
   return SAA_OK;
@@ -809,22 +867,8 @@ int saa_peer_selftest(saa_solver *s, int32_t *ok) {
   if (!s->peer_ready) return fail(SAA_E_STATE, "saa_peer_selftest: saa_peer_attach first");
   if (s->pending) return fail(SAA_E_STATE, "saa_peer_selftest: a synchronised step is in flight");
   HIP_TRY(hipSetDevice(s->device));
-  // every holder contributes rank + 1; the lowest-ranked holder adds 0.25*c so that components differ
-  std::vector<double> own(s->px_iface.n, 0.0);
-  std::vector<unsigned long long> holders(s->px_holders.n);
-  HIP_TRY(hipMemcpy(holders.data(), s->px_holders.p, holders.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-  std::vector<int32_t> slot(std::max<int32_t>(s->n_shared, 0));
-  if (s->n_shared > 0)
-    HIP_TRY(hipMemcpy(slot.data(), s->sh_slot.p, slot.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
-  for (int32_t i = 0; i < s->n_shared; ++i) {
-    const bool lowest = (holders[i] & ((1ull << s->peer.rank) - 1ull)) == 0ull;
-    for (int c = 0; c < 3; ++c) own[3 * static_cast<size_t>(slot[i]) + c] = s->peer.rank + 1 + (lowest ? 0.25 * c : 0.0);
-  }
-  HIP_TRY(hipMemcpyAsync(s->px_iface.p, own.data(), own.size() * sizeof(double), hipMemcpyHostToDevice, s->stream));
-  HIP_TRY(hipStreamSynchronize(s->stream));
   ++s->peer_seq;
-  saa::launch_peer_exchange(s->mesh, s->shared, s->peer, s->stream, nullptr, nullptr, nullptr, s->px_iface.p, nullptr,
-                            s->px_test.p, s->consts, s->peer_seq);
+  saa::launch_peer_selftest(s->peer, s->stream, s->px_own.p, s->px_test.p, s->peer_seq);
   if (int rc = check_launch()) return rc;
   HIP_TRY(hipStreamSynchronize(s->stream));
   int32_t e = 0;
@@ -833,9 +877,10 @@ int saa_peer_selftest(saa_solver *s, int32_t *ok) {
   if (!got.empty()) HIP_TRY(hipMemcpy(got.data(), s->px_test.p, got.size() * sizeof(double), hipMemcpyDeviceToHost));
   bool good = e == 0;
   for (size_t i = 0; i < got.size() && good; ++i) good = got[i] == s->px_expected[i];
-  if (e != 0) {  // leave the error flag clean for a later, agreed fallback decision
+  if (e != 0) {  // the caller falls back to the all-reduce: do not poison later saa_synchronize calls
     const int32_t zero = 0;
     HIP_TRY(hipMemcpy(s->px_err.p, &zero, sizeof(zero), hipMemcpyHostToDevice));
+    s->peer_ready = false;
   }
   *ok = good ? 1 : 0;
   return SAA_OK;
@@ -849,12 +894,10 @@ int saa_step_peer(saa_solver *s, int32_t nsteps, double *hist_dev, int64_t hist_
   const int64_t width = 3 * static_cast<int64_t>(s->n_shared);
   for (int32_t k = 0; k < nsteps; ++k) {
     s->set_ramp();
-    saa::launch_fused_step(s->mesh, s->threads, s->lds_bytes, s->stream, s->dbuf[s->i0].p, s->dbuf[s->in_].p,
-                           s->dbuf[s->i1].p, s->px_iface.p, nullptr, nullptr, s->consts);
-    ++s->peer_seq;
-    saa::launch_peer_exchange(s->mesh, s->shared, s->peer, s->stream, s->dbuf[s->i0].p, s->dbuf[s->in_].p,
-                              s->dbuf[s->i1].p, s->px_iface.p, hist_dev ? hist_dev + (hist_row0 + k) * width : nullptr,
-                              nullptr, s->consts, s->peer_seq);
+    if (++s->peer_seq == 0) ++s->peer_seq;  // 0 marks "never written"
+    saa::launch_fused_step_peer(s->mesh, s->threads, s->lds_bytes, s->stream, s->dbuf[s->i0].p, s->dbuf[s->in_].p,
+                                s->dbuf[s->i1].p, hist_dev ? hist_dev + (hist_row0 + k) * width : nullptr, s->consts,
+                                s->peer, s->peer_seq);
     s->rotate();
     s->tn = s->tn + s->consts.dt;
   }

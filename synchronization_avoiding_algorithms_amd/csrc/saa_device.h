@@ -43,30 +43,37 @@ struct SharedMap {
 };
 
 // Direct peer exchange of the shared-node forces (saa_peer_attach): every rank owns an "inbox" in fine-grained
-// device memory that its neighbours (ranks holding at least one common shared node) write over xGMI.
-//   inbox layout (doubles): [parity 0|1][sender rank 0..world-1][3 * n_shared of the OWNER, owner's shared order]
-//   flags (uint64)        : flags[sender] = sequence number of the last step whose forces have fully arrived
+// device memory that its neighbours (ranks holding at least one common shared node) write over xGMI, inside the
+// fused step kernel.  Low-latency protocol: every fp64 value travels as ONE 16-byte entry of two 8-byte words, each
+// carrying 32 bits of the value and the 32-bit sequence number of the step, so data and "ready" flag arrive together
+// and every word validates itself; the receiver polls the entry - no fence, no separate flag, no collective.
+//   inbox (PeerEntry): [parity 0|1][sender rank 0..world-1][3 * n_shared of the OWNER]; within a sender's segment the
+//   entries follow the SENDER's push order (its common nodes in internal-node order), so that the 64 lanes of a
+//   pushing wave write 1 KiB of contiguous remote memory (full xGMI packets instead of 8-byte ones).
+struct PeerEntry {
+  unsigned long long lo, hi;  // (seq << 32) | low / high half of the double
+};
 struct PeerMap {
-  // sender side: one entry per (neighbour, common shared node)
-  const int32_t *push_src;               // (n_push) index in this rank's shared list
-  double *const *push_dst;               // (n_push) remote address of component 0 in the neighbour's parity-0 inbox
-  const int64_t *push_pstride;           // (n_push) doubles between that neighbour's parity-0 and parity-1 inbox
-  unsigned long long *const *nb_flag;    // (n_nb)   remote address of flags[this rank] in the neighbour's memory
-  const int32_t *nb_rank;                // (n_nb)   neighbour ranks, ascending
-  // receiver side
-  const unsigned long long *flags;       // (world)  this rank's flags
-  const double *inbox;                   // this rank's inbox
-  const unsigned long long *holders;     // (n_shared) bit p set: rank p holds that shared node
-  unsigned int *counter;                 // workgroups of the current launch that have pushed
-  int32_t *err;                          // set to 1 when a wait timed out
-  int64_t timeout_ticks;                 // wall_clock64() ticks (100 MHz) before a wait gives up
-  int32_t n_push, n_nb, rank, world;
+  const int32_t *blk_off;             // (n_blocks + 1) plan block -> range in the node-sorted shared list
+  const int32_t *node;                // (n_shared) internal node id, ascending
+  const int32_t *sidx;                // (n_shared) position in the caller's shared list
+  const unsigned long long *holders;  // (n_shared) bit p set: rank p holds that node
+  const int32_t *nb_off;              // (n_shared + 1) range of neighbour entries of that node (other holders, by rank)
+  PeerEntry *const *push_dst;         // (n_nb) remote address of component 0 in that neighbour's parity-0 inbox
+  const int64_t *push_pstride;        // (n_nb) entries between that neighbour's parity-0 and parity-1 inbox
+  const int64_t *recv_idx;            // (n_nb) entry index of component 0 in THIS rank's parity-0 inbox
+  const PeerEntry *inbox;             // this rank's inbox
+  int64_t parity_stride;              // entries between this rank's parity-0 and parity-1 inbox
+  int32_t *err;                       // set to 1 when a wait timed out
+  int64_t timeout_ticks;              // wall_clock64() ticks (100 MHz) before a wait gives up
+  int32_t rank, world, n_shared;
 };
 
+void launch_fused_step_peer(const DeviceMesh &m, int threads, int lds_bytes, hipStream_t st, const double *d0,
+                            const double *dn, double *d1, double *hist_row, const StepConsts &k, const PeerMap &pm,
+                            unsigned seq);
+void launch_peer_selftest(const PeerMap &pm, hipStream_t st, const double *own, double *out, unsigned seq);
 hipError_t configure_kernels(int lds_bytes);
-void launch_peer_exchange(const DeviceMesh &m, const SharedMap &sh, const PeerMap &pm, hipStream_t st,
-                          const double *d0, const double *dn, double *d1, const double *iface, double *hist_row,
-                          double *test_out, const StepConsts &k, unsigned long long seq);
 void launch_fused_step(const DeviceMesh &m, int threads, int lds_bytes, hipStream_t st, const double *d0,
                        const double *dn, double *d1, double *iface, const double *table_row, double *hist_row,
                        const StepConsts &k);

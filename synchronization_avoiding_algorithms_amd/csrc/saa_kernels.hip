@@ -253,14 +253,67 @@ constexpr int kPreHalo = SAA_KPRE_HALO;
 // element wait for every prefetch in front of it.
 constexpr int kPreConn = SAA_KPRE_CONN;
 
+// ---------------------------------------------------------------------------------------------
+// Direct peer exchange (saa_device.h: PeerMap).  Inboxes are double-buffered by sequence parity: a neighbour can be
+// at most one step ahead, because its step seq+1 cannot end before it has received this rank's push of step seq+1,
+// which is issued only after this rank has consumed step seq.
+// ---------------------------------------------------------------------------------------------
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void peer_push(const PeerMap &pm, int q, int c, double f, unsigned seq) {
+  const unsigned long long b = (unsigned long long)__double_as_longlong(f);
+  const u32x4 w = {(unsigned)b, seq, (unsigned)(b >> 32), seq};
+  const int64_t par = seq & 1u;
+  for (int e = pm.nb_off[q]; e < pm.nb_off[q + 1]; ++e) {
+    PeerEntry *d = pm.push_dst[e] + par * pm.push_pstride[e] + c;
+    // one 16-byte store, system scope (write-through to the peer); each 8-byte half validates itself
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(d), "v"(w) : "memory");
+  }
+}
+// Force of shared node q, component c, summed over the holding ranks in RANK ORDER (the order of syn_cpus,
+// Distributed_tools.py:84-86: identical bits on every rank); waits - bounded - for the neighbours' values.
+__device__ __forceinline__ double peer_collect(const PeerMap &pm, int q, int c, double own, unsigned seq) {
+  const unsigned long long held = pm.holders[q];
+  const PeerEntry *in = pm.inbox + (int64_t)(seq & 1u) * pm.parity_stride + c;
+  int e = pm.nb_off[q];
+  double f = 0.0;
+  bool first = true;
+  for (int p = 0; p < pm.world; ++p) {
+    if (!((held >> p) & 1ull)) continue;
+    double v = own;
+    if (p != pm.rank) {
+      const PeerEntry *src = in + pm.recv_idx[e++];
+      const long long t0 = wall_clock64();
+      unsigned long long lo, hi;
+      while (true) {
+        lo = __hip_atomic_load(&src->lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        hi = __hip_atomic_load(&src->hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if ((unsigned)(lo >> 32) == seq && (unsigned)(hi >> 32) == seq) break;
+        if (wall_clock64() - t0 > pm.timeout_ticks) {  // a neighbour died or never attached: report, do not hang
+          __hip_atomic_store(pm.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(2);
+      }
+      v = __longlong_as_double((long long)((hi << 32) | (lo & 0xffffffffull)));
+    }
+    f = first ? v : f + v;
+    first = false;
+  }
+  return f;
+}
+
 // ABLATE (diagnostic builds only, never launched by the product path): 1 = no LDS atomics,
 // 2 = no indexed LDS reads, 3 = no staging loads, 4 = no update phase, 5 = no element phase.
-template <bool FORCE_ONLY, int ABLATE = 0>
+// PEER: synchronised step with the direct peer exchange - shared nodes are pushed to / collected from the
+// neighbour ranks inside this kernel (one launch per step, no collective).
+template <bool FORCE_ONLY, int ABLATE = 0, bool PEER = false>
 __global__ void __launch_bounds__(SAA_LB) fused_step_kernel(DeviceMesh m, const double *__restrict__ d0, const double *__restrict__ dn,
                                   double *__restrict__ out, double *__restrict__ iface,
-                                  const double *__restrict__ table_row, double *__restrict__ hist_row, StepConsts k) {
+                                  const double *__restrict__ table_row, double *__restrict__ hist_row, StepConsts k,
+                                  PeerMap pm, unsigned seq) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  const BlockDesc bd = m.blocks[plan_block(blockIdx.x, m.n_blocks)];
+  const int pblock = plan_block(blockIdx.x, m.n_blocks);
+  const BlockDesc bd = m.blocks[pblock];
   const int tid = threadIdx.x, nt = blockDim.x;
   double *rec = lds;                       // [n_owned + n_halo][6]: x y z ux uy uz
   double *acc = lds + 6 * m.max_local;     // force planes fx | fy | fz, each m.force_stride doubles
@@ -306,13 +359,13 @@ __global__ void __launch_bounds__(SAA_LB) fused_step_kernel(DeviceMesh m, const 
     hx[j] = ABLATE == 3 ? 1.0 * tid : m.xyz[hg[j]];
     hu[j] = ABLATE == 3 ? 1e-3 * tid : d0[hg[j]];
   }
-  double pm[kPreOwn], pf[kPreOwn], pn[kPreOwn];
+  double pm_[kPreOwn], pf[kPreOwn], pn[kPreOwn];
   int32_t ptag[kPreOwn];
   if (!FORCE_ONLY) {
 #pragma unroll
     for (int j = 0; j < kPreOwn; ++j) {
       const int i = min(tid + j * nt, n_own3 - 1);
-      pm[j] = ABLATE == 4 ? 1.0 : (m.mass_node ? m.mass_node[bd.node_start + i / 3] : m.mass[base + i]);
+      pm_[j] = ABLATE == 4 ? 1.0 : (m.mass_node ? m.mass_node[bd.node_start + i / 3] : m.mass[base + i]);
       pf[j] = ABLATE == 4 ? 0.0 : (m.fext_yz ? (i % 3 == 0 ? 0.0 : m.fext_yz[bd.node_start + i / 3]) : m.fext[base + i]);
       pn[j] = ABLATE == 4 ? 0.0 : dn[base + i];
       ptag[j] = ABLATE == 4 ? 0 : m.tag[bd.node_start + i / 3];
@@ -377,6 +430,7 @@ __global__ void __launch_bounds__(SAA_LB) fused_step_kernel(DeviceMesh m, const 
 
   // update of one owned dof from its finished force (and publication / prediction for shared nodes)
   auto finish = [&](int i, double mass, double fpre, double dnv, int32_t tag) {
+    if (PEER && (tag & kTagShared)) return;  // updated below from the force summed over the ranks
     const int n = i / 3, c = i - 3 * n;
     const double f = acc[n + c * fstride];
     if (iface != nullptr && (tag & kTagShared)) iface[3 * (int64_t)(tag >> kTagSlotShift) + c] = f;
@@ -397,7 +451,7 @@ __global__ void __launch_bounds__(SAA_LB) fused_step_kernel(DeviceMesh m, const 
 #pragma unroll
     for (int j = 0; j < kPreOwn; ++j) {
       const int i = tid + j * nt;
-      if (i < n_early3) finish(i, pm[j], pf[j], pn[j], ptag[j]);
+      if (i < n_early3) finish(i, pm_[j], pf[j], pn[j], ptag[j]);
     }
     for (int i = tid + kPreOwn * nt; i < n_early3; i += nt)
       finish(i, m.mass_node ? m.mass_node[bd.node_start + i / 3] : m.mass[base + i],
@@ -444,17 +498,40 @@ __global__ void __launch_bounds__(SAA_LB) fused_step_kernel(DeviceMesh m, const 
     }
     return;
   }
+  // shared nodes of this block: partial forces leave for the neighbour ranks now, their values are collected
+  // after the update of the other nodes (the xGMI flight time hides under it)
+  int sh0 = 0, n_sh3 = 0;
+  if (PEER) {
+    sh0 = pm.blk_off[pblock];
+    n_sh3 = 3 * (pm.blk_off[pblock + 1] - sh0);
+    for (int j = tid; j < n_sh3; j += nt) {
+      const int q = sh0 + j / 3, c = j % 3;
+      peer_push(pm, q, c, acc[(pm.node[q] - bd.node_start) + c * fstride], seq);
+    }
+  }
   const int n_early3 = 3 * bd.n_early;
 #pragma unroll
   for (int j = 0; j < kPreOwn; ++j) {
     const int i = tid + j * nt;
-    if (i >= n_early3 && i < n_own3) finish(i, pm[j], pf[j], pn[j], ptag[j]);
+    if (i >= n_early3 && i < n_own3) finish(i, pm_[j], pf[j], pn[j], ptag[j]);
   }
   for (int i = tid + kPreOwn * nt; i < n_own3; i += nt)
     if (i >= n_early3)
     finish(i, m.mass_node ? m.mass_node[bd.node_start + i / 3] : m.mass[base + i],
            m.fext_yz ? (i % 3 == 0 ? 0.0 : m.fext_yz[bd.node_start + i / 3]) : m.fext[base + i], dn[base + i],
            m.tag[bd.node_start + i / 3]);
+  if (PEER) {
+    for (int j = tid; j < n_sh3; j += nt) {
+      const int q = sh0 + j / 3, c = j % 3;
+      const int node = pm.node[q], n = node - bd.node_start;
+      const double f = peer_collect(pm, q, c, acc[n + c * fstride], seq);
+      const int64_t g = 3 * (int64_t)node + c;
+      double v = cd_update_dof(f, m.fext[g], m.mass[g], rec[6 * n + 3 + c], dn[g], k);  // Dynamic_solver.py:26-32
+      if (m.tag[node] & (1 << c)) v = 0.0;
+      out[g] = v;
+      if (hist_row != nullptr) hist_row[3 * (int64_t)pm.sidx[q] + c] = v;  // Online_predictor.py:260
+    }
+  }
   if (ABLATE == 8) {  // stamps leave through a buffer of their own (passed in place of the history row)
     T[11] = stamp() - tk;  // update phase
     if ((tid & 63) == 0) {
@@ -466,9 +543,22 @@ __global__ void __launch_bounds__(SAA_LB) fused_step_kernel(DeviceMesh m, const 
 }
 
 template __global__ void fused_step_kernel<false>(DeviceMesh, const double *, const double *, double *,
-                                                   double *, const double *, double *, StepConsts);
+                                                   double *, const double *, double *, StepConsts, PeerMap, unsigned);
 template __global__ void fused_step_kernel<true>(DeviceMesh, const double *, const double *, double *,
-                                                  double *, const double *, double *, StepConsts);
+                                                  double *, const double *, double *, StepConsts, PeerMap, unsigned);
+template __global__ void fused_step_kernel<false, 0, true>(DeviceMesh, const double *, const double *, double *,
+                                                            double *, const double *, double *, StepConsts, PeerMap,
+                                                            unsigned);
+
+// Attach-time proof of the peer path: one exchange of known values (own[3*q+c], node-sorted order) -> the sums
+// in the caller's shared order.
+__global__ void peer_selftest_kernel(PeerMap pm, const double *__restrict__ own, double *__restrict__ out,
+                                     unsigned seq) {
+  const int gtid = blockIdx.x * blockDim.x + threadIdx.x, gthreads = gridDim.x * blockDim.x;
+  for (int j = gtid; j < 3 * pm.n_shared; j += gthreads) peer_push(pm, j / 3, j % 3, own[j], seq);
+  for (int j = gtid; j < 3 * pm.n_shared; j += gthreads)
+    out[3 * (int64_t)pm.sidx[j / 3] + j % 3] = peer_collect(pm, j / 3, j % 3, own[j], seq);
+}
 
 // After the all-reduce: shared nodes get the update from the summed force (Dynamic_solver.py:26-32),
 // optional history record (Online_predictor.py:260); slots of shared nodes this rank does not hold
@@ -490,90 +580,6 @@ __global__ void iface_finish_kernel(DeviceMesh m, SharedMap sh, const double *__
   } else if (i < n_local + 3 * sh.n_foreign) {
     const int j = i - n_local;
     iface[3 * (int64_t)sh.foreign_slot[j / 3] + (j % 3)] = 0.0;
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Direct peer exchange (replaces the all-reduce of the synchronised step when saa_peer_attach succeeded).
-// One launch per step, after the fused kernel:
-//   1. push   : this rank's partial force of every shared node goes straight into the inbox of every other rank
-//               holding that node (system-scope stores over xGMI); the LAST workgroup to finish its share raises
-//               flags[this rank] = seq in every neighbour's memory (release, system scope),
-//   2. wait   : until every neighbour's flag in this rank's memory has reached seq (bounded: PeerMap::timeout_ticks),
-//   3. finish : shared nodes get the update from the force summed over the holding ranks in RANK ORDER - the order
-//               of syn_cpus (Distributed_tools.py:84-86), identical bits on every rank - (Dynamic_solver.py:26-32).
-// Inboxes are double-buffered by seq parity: a neighbour can be at most one step ahead, because its step seq+1
-// needs this rank's flag seq+1, which is raised only after this rank's finish of step seq.
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void store_sys(double *p, double v) {
-  __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v),
-                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-__device__ __forceinline__ double load_sys(const double *p) {
-  return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(p),
-                                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
-}
-
-__global__ void __launch_bounds__(256) peer_exchange_kernel(DeviceMesh m, SharedMap sh, PeerMap pm,
-                                                            const double *__restrict__ d0, const double *__restrict__ dn,
-                                                            double *__restrict__ d1, const double *__restrict__ iface,
-                                                            double *__restrict__ hist_row, double *__restrict__ test_out,
-                                                            StepConsts k, unsigned long long seq) {
-  const int gtid = blockIdx.x * blockDim.x + threadIdx.x, gthreads = gridDim.x * blockDim.x;
-  const int64_t parity = (int64_t)(seq & 1ull);
-  // ---- 1. push ------------------------------------------------------------------------------------
-  for (int i = gtid; i < 3 * pm.n_push; i += gthreads) {
-    const int e = i / 3, c = i - 3 * e;
-    const double v = iface[3 * (int64_t)sh.slot[pm.push_src[e]] + c];
-    store_sys(pm.push_dst[e] + parity * pm.push_pstride[e] + c, v);
-  }
-  __threadfence_system();  // this thread's pushes have reached their destination before the workgroup is counted
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const unsigned done = __hip_atomic_fetch_add(pm.counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    if (done == gridDim.x - 1) {
-      __hip_atomic_store(pm.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // next launch is stream-ordered
-      for (int j = 0; j < pm.n_nb; ++j)
-        __hip_atomic_store(pm.nb_flag[j], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-  }
-  // ---- 2. wait for the neighbours' forces of this step -------------------------------------------------
-  for (int j = threadIdx.x; j < pm.n_nb; j += blockDim.x) {
-    const unsigned long long *f = pm.flags + pm.nb_rank[j];
-    const long long t0 = wall_clock64();
-    while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
-      if (wall_clock64() - t0 > pm.timeout_ticks) {  // a neighbour died or never attached: give up, report
-        __hip_atomic_store(pm.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        break;
-      }
-      __builtin_amdgcn_s_sleep(8);
-    }
-  }
-  __syncthreads();
-  // ---- 3. summed force -> update of the shared nodes -----------------------------------------------------
-  const int64_t per_sender = 3 * (int64_t)sh.n_shared;
-  const double *in = pm.inbox + parity * per_sender * pm.world;
-  for (int i = gtid; i < 3 * sh.n_shared; i += gthreads) {
-    const int s = i / 3, c = i - 3 * s;
-    const unsigned long long held = pm.holders[s];
-    double f = 0.0;
-    bool first = true;
-    for (int p = 0; p < pm.world; ++p) {
-      if (!((held >> p) & 1ull)) continue;
-      const double v = p == pm.rank ? iface[3 * (int64_t)sh.slot[s] + c] : load_sys(in + p * per_sender + i);
-      f = first ? v : f + v;
-      first = false;
-    }
-    if (test_out != nullptr) {  // attach-time self-test: report the sums, leave the state alone
-      test_out[i] = f;
-      continue;
-    }
-    const int node = sh.node[s];
-    const int64_t g = 3 * (int64_t)node + c;
-    double v = cd_update_dof(f, m.fext[g], m.mass[g], d0[g], dn[g], k);
-    if (m.tag[node] & (1 << c)) v = 0.0;
-    d1[g] = v;
-    if (hist_row) hist_row[i] = v;
   }
 }
 
@@ -622,7 +628,10 @@ hipError_t configure_kernels(int lds_bytes) {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_step_kernel<false>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
   if (e != hipSuccess) return e;
-  return hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_step_kernel<true>),
+  e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_step_kernel<true>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+  if (e != hipSuccess) return e;
+  return hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_step_kernel<false, 0, true>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
 }
 
@@ -630,7 +639,20 @@ void launch_fused_step(const DeviceMesh &m, int threads, int lds_bytes, hipStrea
                        const double *dn, double *d1, double *iface, const double *table_row, double *hist_row,
                        const StepConsts &k) {
   hipLaunchKernelGGL(fused_step_kernel<false>, dim3(m.n_blocks), dim3(threads), lds_bytes, st, m, d0, dn, d1,
-                     iface, table_row, hist_row, k);
+                     iface, table_row, hist_row, k, PeerMap{}, 0u);
+}
+
+void launch_fused_step_peer(const DeviceMesh &m, int threads, int lds_bytes, hipStream_t st, const double *d0,
+                            const double *dn, double *d1, double *hist_row, const StepConsts &k, const PeerMap &pm,
+                            unsigned seq) {
+  hipLaunchKernelGGL((fused_step_kernel<false, 0, true>), dim3(m.n_blocks), dim3(threads), lds_bytes, st, m, d0, dn,
+                     d1, static_cast<double *>(nullptr), static_cast<const double *>(nullptr), hist_row, k, pm, seq);
+}
+
+void launch_peer_selftest(const PeerMap &pm, hipStream_t st, const double *own, double *out, unsigned seq) {
+  const int n = 3 * pm.n_shared;
+  const int blocks = n == 0 ? 1 : ((n + 255) / 256 < 64 ? (n + 255) / 256 : 64);
+  hipLaunchKernelGGL(peer_selftest_kernel, dim3(blocks), dim3(256), 0, st, pm, own, out, seq);
 }
 
 // Diagnostic only (tools/ablate.py): the step kernel with one phase removed; results are garbage.
@@ -643,7 +665,7 @@ void launch_fused_step_ablated(int variant, const DeviceMesh &m, int threads, in
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_step_kernel<false, V>),                \
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);                      \
     hipLaunchKernelGGL((fused_step_kernel<false, V>), dim3(m.n_blocks), dim3(threads), lds_bytes, st, m, d0, \
-                       dn, d1, none, cnone, V == 8 ? dbg : none, k);                                       \
+                       dn, d1, none, cnone, V == 8 ? dbg : none, k, PeerMap{}, 0u);                        \
     break;
   switch (variant) {
     SAA_ABL(0) SAA_ABL(1) SAA_ABL(2) SAA_ABL(3) SAA_ABL(4) SAA_ABL(5) SAA_ABL(6) SAA_ABL(7) SAA_ABL(8)
@@ -657,7 +679,7 @@ void launch_force_only(const DeviceMesh &m, int threads, int lds_bytes, hipStrea
   StepConsts k{};
   hipLaunchKernelGGL(fused_step_kernel<true>, dim3(m.n_blocks), dim3(threads), lds_bytes, st, m, d, d, f,
                      static_cast<double *>(nullptr), static_cast<const double *>(nullptr),
-                     static_cast<double *>(nullptr), k);
+                     static_cast<double *>(nullptr), k, PeerMap{}, 0u);
 }
 
 void launch_iface_finish(const DeviceMesh &m, const SharedMap &sh, hipStream_t st, const double *d0,
@@ -666,16 +688,6 @@ void launch_iface_finish(const DeviceMesh &m, const SharedMap &sh, hipStream_t s
   if (n == 0) return;
   hipLaunchKernelGGL(iface_finish_kernel, dim3((n + 255) / 256), dim3(256), 0, st, m, sh, d0, dn, d1, iface,
                      hist_row, k);
-}
-
-void launch_peer_exchange(const DeviceMesh &m, const SharedMap &sh, const PeerMap &pm, hipStream_t st,
-                          const double *d0, const double *dn, double *d1, const double *iface, double *hist_row,
-                          double *test_out, const StepConsts &k, unsigned long long seq) {
-  // few, always co-resident workgroups: every one of them waits for the neighbours inside the kernel
-  const int n = 3 * (pm.n_push > sh.n_shared ? pm.n_push : sh.n_shared);
-  const int blocks = n == 0 ? 1 : ((n + 255) / 256 < 64 ? (n + 255) / 256 : 64);
-  hipLaunchKernelGGL(peer_exchange_kernel, dim3(blocks), dim3(256), 0, st, m, sh, pm, d0, dn, d1, iface, hist_row,
-                     test_out, k, seq);
 }
 
 void launch_halo_overwrite(const SharedMap &sh, hipStream_t st, const double *row, double *d1, double *hist_row) {

@@ -102,19 +102,20 @@ class PartitionedSolver:
 
         if not hasattr(self.solver, "peer_export") or self.world > 64:
             return self._agree(False) and False
-        ok, handle = 1, bytes(64)
+        slots = np.asarray(self.layout.shared_slots, dtype=np.int32)
+        ok, handle, order = 1, bytes(64), np.zeros(len(slots), dtype=np.int32)
         try:
-            handle = self.solver.peer_export(self.world)
+            handle, order = self.solver.peer_export(self.world)
         except Exception:  # noqa: BLE001
             ok = 0
-        info = (ok, handle, self.device_ordinal, np.asarray(self.layout.shared_slots, dtype=np.int32))
+        info = (ok, handle, self.device_ordinal, slots, order)
         box = [None] * self.world
         dist.all_gather_object(box, info, group=self.group)
         if min(b[0] for b in box) == 0:
             return False
         try:
             self.solver.peer_attach(self.rank, self.world, [b[1] for b in box], [b[2] for b in box],
-                                    [b[3] for b in box])
+                                    [b[3] for b in box], [b[4] for b in box])
         except Exception:  # noqa: BLE001
             ok = 0
         if not self._agree(ok):  # also the barrier: every inbox is mapped before anybody pushes

@@ -184,23 +184,31 @@ class HipExplicitSolver:
         _lib.check(self._lib.saa_step_synced(self._h, int(nsteps), _dev(hist), int(hist_row0)))
 
     # -- direct peer exchange (xGMI peer stores, no collective) -------------------------------------
-    def peer_export(self, world: int) -> bytes:
+    def peer_export(self, world: int):
+        """Returns ``(handle, order)``: the 64-byte IPC handle of this rank's inbox and, per shared node, its
+        position in this rank's push order; both are all-gathered by the caller."""
         buf = (C.c_uint8 * 64)()
-        _lib.check(self._lib.saa_peer_export(self._h, int(world), buf))
-        return bytes(buf)
+        order = np.zeros(max(self.n_shared, 1), dtype=np.int32)
+        _lib.check(self._lib.saa_peer_export(self._h, int(world), buf, order.ctypes.data_as(C.POINTER(C.c_int32))))
+        return bytes(buf), order[:self.n_shared]
 
-    def peer_attach(self, rank: int, world: int, handles, devices, slot_lists):
-        """``handles``: per-rank 64-byte IPC handles; ``devices``: per-rank HIP ordinals; ``slot_lists``:
-        per-rank ``shared_slots`` arrays (all as all-gathered by the caller)."""
+    def peer_attach(self, rank: int, world: int, handles, devices, slot_lists, order_lists):
+        """``handles``: per-rank 64-byte IPC handles; ``devices``: per-rank HIP ordinals; ``slot_lists`` /
+        ``order_lists``: per-rank ``shared_slots`` and push orders (all as all-gathered by the caller)."""
+        def cat(lists):
+            n = sum(len(x) for x in lists)
+            return _i32(np.concatenate([np.asarray(x, dtype=np.int32).reshape(-1) for x in lists]) if n
+                        else np.zeros(1, dtype=np.int32))
+
+        if [len(x) for x in slot_lists] != [len(x) for x in order_lists]:
+            raise ValueError("slot and order lists differ in length")
         hb = (C.c_uint8 * (64 * world)).from_buffer_copy(b"".join(handles))
-        dev = _i32(devices)
-        counts = _i32([len(x) for x in slot_lists])
-        cat = _i32(np.concatenate([np.asarray(x, dtype=np.int32).reshape(-1) for x in slot_lists])
-                   if sum(len(x) for x in slot_lists) else np.zeros(1, dtype=np.int32))
-        _lib.check(self._lib.saa_peer_attach(self._h, int(rank), int(world), hb,
-                                             dev.ctypes.data_as(C.POINTER(C.c_int32)),
-                                             counts.ctypes.data_as(C.POINTER(C.c_int32)),
-                                             cat.ctypes.data_as(C.POINTER(C.c_int32))))
+        dev, counts = _i32(devices), _i32([len(x) for x in slot_lists])
+        slots, orders = cat(slot_lists), cat(order_lists)
+        p32 = C.POINTER(C.c_int32)
+        _lib.check(self._lib.saa_peer_attach(self._h, int(rank), int(world), hb, dev.ctypes.data_as(p32),
+                                             counts.ctypes.data_as(p32), slots.ctypes.data_as(p32),
+                                             orders.ctypes.data_as(p32)))
 
     def peer_selftest(self) -> bool:
         ok = C.c_int32()
