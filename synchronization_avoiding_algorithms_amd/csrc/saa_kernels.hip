@@ -12,12 +12,14 @@
 //      (ds_add_f64) - no global atomics, no force vector in HBM,
 //   3. applies the damped central-difference update of Tools/Dynamic_solver.py:13-20 to its owned
 //      dofs in the reference's association order (no FMA contraction) and writes d^(n+1); shared nodes
-//      additionally publish their partial force (synchronised mode) or take the LSTM prediction and
+//      additionally publish their partial force (synchronised mode; with the peer exchange they are pushed to
+//      the neighbour ranks' memory and summed right here, PEER variant) or take the LSTM prediction and
 //      record it as history (sync-avoiding mode, Online_predictor.py:298-301).
 // The same kernel in FORCE_ONLY mode writes f_int instead (backs LocalK.dot, Dynamic_solver.py:12).
 //
 // Bandwidth-bound gather/scatter in fp64: MFMA is not used (and fp64 MFMA has the vector rate on
-// gfx950 anyway).  64-wide waves; all cross-workgroup data flows through kernel boundaries.
+// gfx950 anyway).  64-wide waves; cross-workgroup data flows through kernel boundaries (cross-RANK data of the
+// PEER variant through self-validating entries in fine-grained memory).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
