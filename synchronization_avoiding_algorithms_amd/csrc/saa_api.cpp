@@ -4,6 +4,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <climits>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -124,6 +125,9 @@ struct saa_solver {
   DevBuf<int32_t> px_blk_off, px_node, px_sidx, px_nb_off, px_err;
   DevBuf<saa::PeerEntry *> px_dst;
   DevBuf<int64_t> px_pstride, px_recv;
+  DevBuf<saa::PeerPushRec> px_push_rec;
+  DevBuf<saa::PeerRecvRec> px_recv_rec;
+  DevBuf<saa::PeerMap> px_map;  // device copy of `peer` (the step kernel reads it from memory)
   DevBuf<unsigned long long> px_holders;
   DevBuf<double> px_own, px_test;
   std::vector<double> px_expected;   // self-test: expected sums
@@ -148,7 +152,7 @@ struct saa_solver {
     if (peer_mem) (void)hipFree(peer_mem);
     peer_mem = nullptr;
     px_blk_off.release(); px_node.release(); px_sidx.release(); px_nb_off.release(); px_err.release();
-    px_dst.release(); px_pstride.release(); px_recv.release(); px_holders.release(); px_own.release(); px_test.release();
+    px_dst.release(); px_pstride.release(); px_recv.release(); px_push_rec.release(); px_recv_rec.release(); px_map.release(); px_holders.release(); px_own.release(); px_test.release();
   }
 };
 
@@ -697,9 +701,12 @@ int saa_peer_export(saa_solver *s, int32_t world, uint8_t handle_out[64], int32_
   return SAA_OK;
 }
 
-int saa_peer_attach(saa_solver *s, int32_t rank, int32_t world, const uint8_t *handles, const int32_t *devices,
-                    const int32_t *slot_counts, const int32_t *slots, const int32_t *orders) {
-  if (!s || !handles || !devices || !slot_counts || !slots || !orders || world < 2 || rank < 0 || rank >= world)
+// loopback (diagnostic, tools/peer_loopback.py): the "neighbours" live in this rank's own inbox, so that the cost of
+// the push / collect phases of the PEER kernel can be timed on a one-GPU box (local instead of xGMI latency).
+static int peer_attach_impl(saa_solver *s, int32_t rank, int32_t world, const uint8_t *handles, const int32_t *devices,
+                            const int32_t *slot_counts, const int32_t *slots, const int32_t *orders, bool loopback) {
+  if (!s || (!loopback && (!handles || !devices)) || !slot_counts || !slots || !orders || world < 2 || rank < 0 ||
+      rank >= world)
     return fail(SAA_E_ARG, "saa_peer_attach: bad argument");
   if (!s->peer_mem || s->peer_world != world) return fail(SAA_E_STATE, "saa_peer_attach: saa_peer_export(world) first");
   if (s->peer_ready) return fail(SAA_E_STATE, "saa_peer_attach: already attached");
@@ -766,21 +773,24 @@ int saa_peer_attach(saa_solver *s, int32_t rank, int32_t world, const uint8_t *h
       if (q >= 0) common.push_back({q, orders[off[p] + j]});
     }
     if (common.empty()) continue;
-    hipIpcMemHandle_t h;
-    std::memcpy(&h, handles + 64 * static_cast<size_t>(p), 64);
-    if (devices[p] != s->device) {
-      int can = 0;
-      (void)hipDeviceCanAccessPeer(&can, s->device, devices[p]);
-      if (can) (void)hipDeviceEnablePeerAccess(devices[p], 0);  // "already enabled" is fine; the self-test decides
-      (void)hipGetLastError();
+    void *base = s->peer_mem;
+    if (!loopback) {
+      hipIpcMemHandle_t h;
+      std::memcpy(&h, handles + 64 * static_cast<size_t>(p), 64);
+      if (devices[p] != s->device) {
+        int can = 0;
+        (void)hipDeviceCanAccessPeer(&can, s->device, devices[p]);
+        if (can) (void)hipDeviceEnablePeerAccess(devices[p], 0);  // "already enabled" is fine; the self-test decides
+        (void)hipGetLastError();
+      }
+      base = nullptr;
+      const hipError_t oe = hipIpcOpenMemHandle(&base, h, hipIpcMemLazyEnablePeerAccess);
+      if (oe != hipSuccess || !base) {
+        (void)hipGetLastError();
+        return fail(SAA_E_HIP, "saa_peer_attach: hipIpcOpenMemHandle(rank " + std::to_string(p) + "): " + hipGetErrorString(oe));
+      }
+      s->peer_open.push_back(base);
     }
-    void *base = nullptr;
-    const hipError_t oe = hipIpcOpenMemHandle(&base, h, hipIpcMemLazyEnablePeerAccess);
-    if (oe != hipSuccess || !base) {
-      (void)hipGetLastError();
-      return fail(SAA_E_HIP, "saa_peer_attach: hipIpcOpenMemHandle(rank " + std::to_string(p) + "): " + hipGetErrorString(oe));
-    }
-    s->peer_open.push_back(base);
     const int64_t per_p = 3 * static_cast<int64_t>(std::max<int32_t>(slot_counts[p], 1));
     saa::PeerEntry *inbox_p = static_cast<saa::PeerEntry *>(base);
     // position of every common node in MY push order (what I write) and in p's push order (what I read)
@@ -792,7 +802,7 @@ int saa_peer_attach(saa_solver *s, int32_t rank, int32_t world, const uint8_t *h
     for (size_t t = 0; t < by.size(); ++t) t_recv[by[t]] = static_cast<int32_t>(t);
     for (size_t i = 0; i < common.size(); ++i) {
       holders[common[i].q] |= 1ull << p;
-      nbs[common[i].q].push_back({p, inbox_p + rank * per_p + 3 * static_cast<int64_t>(t_send[i]), per_p * world,
+      nbs[common[i].q].push_back({p, inbox_p + (loopback ? p : rank) * per_p + 3 * static_cast<int64_t>(t_send[i]), per_p * world,
                                   p * per_me + 3 * static_cast<int64_t>(t_recv[i])});
     }
   }
@@ -808,6 +818,16 @@ int saa_peer_attach(saa_solver *s, int32_t rank, int32_t world, const uint8_t *h
     }
   }
   nb_off[nsh] = static_cast<int32_t>(push_dst.size());
+  std::vector<saa::PeerPushRec> push_rec(std::max<int32_t>(nsh, 1));
+  std::vector<saa::PeerRecvRec> recv_rec(std::max<int32_t>(nsh, 1));
+  for (size_t b = 0; b < s->plan.blocks.size(); ++b)
+    for (int32_t q = blk_off[b]; q < blk_off[b + 1]; ++q) {
+      const Nb f = nbs[q].empty() ? Nb{rank, nullptr, 0, 0} : nbs[q].front();
+      if (f.pstride > INT32_MAX || f.recv > INT32_MAX) return fail(SAA_E_CAPACITY, "saa_peer_attach: inbox too large");
+      push_rec[q] = {f.dst, static_cast<int32_t>(f.pstride),
+                     (node[q] - s->plan.blocks[b].node_start) | (static_cast<int32_t>(nbs[q].size()) << 16)};
+      recv_rec[q] = {holders[q], static_cast<int32_t>(f.recv), sidx[q]};
+    }
   if (push_dst.empty()) {  // keep the device arrays non-null
     push_dst.push_back(nullptr);
     push_pstride.push_back(0);
@@ -834,6 +854,8 @@ int saa_peer_attach(saa_solver *s, int32_t rank, int32_t world, const uint8_t *h
   HIP_TRY(s->px_dst.upload(push_dst));
   HIP_TRY(s->px_pstride.upload(push_pstride));
   HIP_TRY(s->px_recv.upload(recv_idx));
+  HIP_TRY(s->px_push_rec.upload(push_rec));
+  HIP_TRY(s->px_recv_rec.upload(recv_rec));
   HIP_TRY(s->px_holders.upload(holders));
   HIP_TRY(s->px_err.upload(std::vector<int32_t>(1, 0)));
   HIP_TRY(s->px_own.upload(own));
@@ -843,6 +865,8 @@ int saa_peer_attach(saa_solver *s, int32_t rank, int32_t world, const uint8_t *h
   pm.node = s->px_node.p;
   pm.sidx = s->px_sidx.p;
   pm.holders = s->px_holders.p;
+  pm.push_rec = s->px_push_rec.p;
+  pm.recv_rec = s->px_recv_rec.p;
   pm.nb_off = s->px_nb_off.p;
   pm.push_dst = s->px_dst.p;
   pm.push_pstride = s->px_pstride.p;
@@ -856,9 +880,15 @@ int saa_peer_attach(saa_solver *s, int32_t rank, int32_t world, const uint8_t *h
   pm.rank = rank;
   pm.world = world;
   pm.n_shared = nsh;
+  HIP_TRY(s->px_map.upload(std::vector<saa::PeerMap>(1, pm)));
   s->peer_seq = 0;
   s->peer_ready = true;
   return SAA_OK;
+}
+
+int saa_peer_attach(saa_solver *s, int32_t rank, int32_t world, const uint8_t *handles, const int32_t *devices,
+                    const int32_t *slot_counts, const int32_t *slots, const int32_t *orders) {
+  return peer_attach_impl(s, rank, world, handles, devices, slot_counts, slots, orders, false);
 }
 
 int saa_peer_selftest(saa_solver *s, int32_t *ok) {
@@ -897,7 +927,7 @@ int saa_step_peer(saa_solver *s, int32_t nsteps, double *hist_dev, int64_t hist_
     if (++s->peer_seq == 0) ++s->peer_seq;  // 0 marks "never written"
     saa::launch_fused_step_peer(s->mesh, s->threads, s->lds_bytes, s->stream, s->dbuf[s->i0].p, s->dbuf[s->in_].p,
                                 s->dbuf[s->i1].p, hist_dev ? hist_dev + (hist_row0 + k) * width : nullptr, s->consts,
-                                s->peer, s->peer_seq);
+                                s->px_map.p, s->peer_seq);
     s->rotate();
     s->tn = s->tn + s->consts.dt;
   }
@@ -988,6 +1018,41 @@ int saa_debug_time_ablated(saa_solver *s, int32_t variant, int32_t nsteps, doubl
   (void)hipEventDestroy(a);
   (void)hipEventDestroy(b);
   return check_launch();
+}
+
+// Diagnostic, not part of include/saa_hip.h (tools/peer_loopback.py): attach this rank to `world - 1` imaginary
+// neighbours that hold exactly the same shared nodes and whose inbox segments live in this rank's own inbox, then
+// time saa_step_peer.  Every shared force comes back (world - 1) times: the state is meaningless.
+int saa_debug_peer_loopback(saa_solver *s, int32_t world) {
+  if (!s || world < 2 || world > 8 || s->n_shared <= 0) return fail(SAA_E_ARG, "saa_debug_peer_loopback: bad argument");
+  uint8_t handle[64];
+  std::vector<int32_t> order(s->n_shared);
+  if (int rc = saa_peer_export(s, world, handle, order.data())) return rc;
+  std::vector<int32_t> my_slots(s->n_shared), counts(world, s->n_shared), slots, orders;
+  HIP_TRY(hipMemcpy(my_slots.data(), s->sh_slot.p, my_slots.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+  for (int p = 0; p < world; ++p) {
+    slots.insert(slots.end(), my_slots.begin(), my_slots.end());
+    orders.insert(orders.end(), order.begin(), order.end());
+  }
+  return peer_attach_impl(s, 0, world, nullptr, nullptr, counts.data(), slots.data(), orders.data(), true);
+}
+
+int saa_debug_time_peer(saa_solver *s, int32_t nsteps, double *elapsed_ms) {
+  if (!s || !elapsed_ms || nsteps < 0) return fail(SAA_E_ARG, "saa_debug_time_peer: bad argument");
+  HIP_TRY(hipSetDevice(s->device));
+  hipEvent_t a, b;
+  HIP_TRY(hipEventCreate(&a));
+  HIP_TRY(hipEventCreate(&b));
+  HIP_TRY(hipEventRecord(a, s->stream));
+  int rc = saa_step_peer(s, nsteps, nullptr, 0);
+  HIP_TRY(hipEventRecord(b, s->stream));
+  HIP_TRY(hipEventSynchronize(b));
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, a, b));
+  *elapsed_ms = ms;
+  (void)hipEventDestroy(a);
+  (void)hipEventDestroy(b);
+  return rc ? rc : check_peer_error(s);
 }
 
 // Diagnostic: copies the stamps of the last variant-8 launch to the host (n = 12 * blocks * waves values).

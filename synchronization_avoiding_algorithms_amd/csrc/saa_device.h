@@ -53,7 +53,21 @@ struct SharedMap {
 struct PeerEntry {
   unsigned long long lo, hi;  // (seq << 32) | low / high half of the double
 };
+// One 16-byte load each gives a pushing / collecting lane everything it needs for a node with ONE other holder
+// (a dependent chain of index loads would sit on the kernel's tail); further holders use the generic lists.
+struct PeerPushRec {
+  PeerEntry *dst0;     // first neighbour: remote address of component 0, parity 0
+  int32_t pstride0;    // entries between that neighbour's parity-0 and parity-1 inbox
+  int32_t info;        // bits 0..15 node index inside its plan block, bits 16.. number of neighbours
+};
+struct PeerRecvRec {
+  unsigned long long holders;  // bit p set: rank p holds that node
+  int32_t recv0;               // first neighbour: entry index of component 0 in this rank's parity-0 inbox
+  int32_t sidx;                // position in the caller's shared list
+};
 struct PeerMap {
+  const PeerPushRec *push_rec;        // (n_shared)
+  const PeerRecvRec *recv_rec;        // (n_shared)
   const int32_t *blk_off;             // (n_blocks + 1) plan block -> range in the node-sorted shared list
   const int32_t *node;                // (n_shared) internal node id, ascending
   const int32_t *sidx;                // (n_shared) position in the caller's shared list
@@ -70,8 +84,8 @@ struct PeerMap {
 };
 
 void launch_fused_step_peer(const DeviceMesh &m, int threads, int lds_bytes, hipStream_t st, const double *d0,
-                            const double *dn, double *d1, double *hist_row, const StepConsts &k, const PeerMap &pm,
-                            unsigned seq);
+                            const double *dn, double *d1, double *hist_row, const StepConsts &k,
+                            const PeerMap *pm_dev, unsigned seq);
 void launch_peer_selftest(const PeerMap &pm, hipStream_t st, const double *own, double *out, unsigned seq);
 hipError_t configure_kernels(int lds_bytes);
 void launch_fused_step(const DeviceMesh &m, int threads, int lds_bytes, hipStream_t st, const double *d0,

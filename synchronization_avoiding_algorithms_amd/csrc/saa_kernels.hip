@@ -261,43 +261,51 @@ constexpr int kPreConn = SAA_KPRE_CONN;
 // which is issued only after this rank has consumed step seq.
 // ---------------------------------------------------------------------------------------------
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void peer_push(const PeerMap &pm, int q, int c, double f, unsigned seq) {
+__device__ __forceinline__ void peer_store(PeerEntry *d, double f, unsigned seq) {
   const unsigned long long b = (unsigned long long)__double_as_longlong(f);
   const u32x4 w = {(unsigned)b, seq, (unsigned)(b >> 32), seq};
+  // one 16-byte store, system scope (write-through to the peer); each 8-byte half validates itself
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(d), "v"(w) : "memory");
+}
+__device__ __forceinline__ void peer_push(const PeerMap &pm, const PeerPushRec &r, int q, int c, double f, unsigned seq) {
   const int64_t par = seq & 1u;
-  for (int e = pm.nb_off[q]; e < pm.nb_off[q + 1]; ++e) {
-    PeerEntry *d = pm.push_dst[e] + par * pm.push_pstride[e] + c;
-    // one 16-byte store, system scope (write-through to the peer); each 8-byte half validates itself
-    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(d), "v"(w) : "memory");
+  const int n_nb = r.info >> 16;
+  if (n_nb > 0) peer_store(r.dst0 + par * r.pstride0 + c, f, seq);
+  if (n_nb > 1) {  // node held by three or more ranks
+    const int e0 = pm.nb_off[q];
+    for (int e = e0 + 1; e < e0 + n_nb; ++e) peer_store(pm.push_dst[e] + par * pm.push_pstride[e] + c, f, seq);
   }
 }
+// One neighbour's value of this step: polls - bounded - until both halves carry the step's sequence number.
+__device__ __forceinline__ double peer_wait(const PeerMap &pm, const PeerEntry *src, unsigned seq) {
+  const long long t0 = wall_clock64();
+  unsigned long long lo, hi;
+  while (true) {
+    lo = __hip_atomic_load(&src->lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    hi = __hip_atomic_load(&src->hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if ((unsigned)(lo >> 32) == seq && (unsigned)(hi >> 32) == seq) break;
+    if (wall_clock64() - t0 > pm.timeout_ticks) {  // a neighbour died or never attached: report, do not hang
+      __hip_atomic_store(pm.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      break;
+    }
+    __builtin_amdgcn_s_sleep(2);
+  }
+  return __longlong_as_double((long long)((hi << 32) | (lo & 0xffffffffull)));
+}
 // Force of shared node q, component c, summed over the holding ranks in RANK ORDER (the order of syn_cpus,
-// Distributed_tools.py:84-86: identical bits on every rank); waits - bounded - for the neighbours' values.
-__device__ __forceinline__ double peer_collect(const PeerMap &pm, int q, int c, double own, unsigned seq) {
-  const unsigned long long held = pm.holders[q];
+// Distributed_tools.py:84-86: identical bits on every rank).
+__device__ __forceinline__ double peer_collect(const PeerMap &pm, const PeerRecvRec &r, int q, int c, double own,
+                                               unsigned seq) {
   const PeerEntry *in = pm.inbox + (int64_t)(seq & 1u) * pm.parity_stride + c;
+  const unsigned long long others = r.holders & ~(1ull << pm.rank);
+  if (others == 0ull) return own;  // declared shared, held by this rank only
+  if ((others & (others - 1ull)) == 0ull) return own + peer_wait(pm, in + r.recv0, seq);  // one other holder: a + b == b + a
   int e = pm.nb_off[q];
   double f = 0.0;
   bool first = true;
   for (int p = 0; p < pm.world; ++p) {
-    if (!((held >> p) & 1ull)) continue;
-    double v = own;
-    if (p != pm.rank) {
-      const PeerEntry *src = in + pm.recv_idx[e++];
-      const long long t0 = wall_clock64();
-      unsigned long long lo, hi;
-      while (true) {
-        lo = __hip_atomic_load(&src->lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        hi = __hip_atomic_load(&src->hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        if ((unsigned)(lo >> 32) == seq && (unsigned)(hi >> 32) == seq) break;
-        if (wall_clock64() - t0 > pm.timeout_ticks) {  // a neighbour died or never attached: report, do not hang
-          __hip_atomic_store(pm.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-          break;
-        }
-        __builtin_amdgcn_s_sleep(2);
-      }
-      v = __longlong_as_double((long long)((hi << 32) | (lo & 0xffffffffull)));
-    }
+    if (!((r.holders >> p) & 1ull)) continue;
+    const double v = p == pm.rank ? own : peer_wait(pm, in + pm.recv_idx[e++], seq);
     f = first ? v : f + v;
     first = false;
   }
@@ -312,7 +320,7 @@ template <bool FORCE_ONLY, int ABLATE = 0, bool PEER = false>
 __global__ void __launch_bounds__(SAA_LB) fused_step_kernel(DeviceMesh m, const double *__restrict__ d0, const double *__restrict__ dn,
                                   double *__restrict__ out, double *__restrict__ iface,
                                   const double *__restrict__ table_row, double *__restrict__ hist_row, StepConsts k,
-                                  PeerMap pm, unsigned seq) {
+                                  const PeerMap *__restrict__ pmap, unsigned seq) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int pblock = plan_block(blockIdx.x, m.n_blocks);
   const BlockDesc bd = m.blocks[pblock];
@@ -502,13 +510,18 @@ __global__ void __launch_bounds__(SAA_LB) fused_step_kernel(DeviceMesh m, const 
   }
   // shared nodes of this block: partial forces leave for the neighbour ranks now, their values are collected
   // after the update of the other nodes (the xGMI flight time hides under it)
+  // (the map is read from device memory HERE, not passed by value: a by-value copy would sit in SGPRs through
+  // the element phase, which has none to spare)
   int sh0 = 0, n_sh3 = 0;
+  PeerMap pm{};
   if (PEER) {
+    pm = *pmap;
     sh0 = pm.blk_off[pblock];
     n_sh3 = 3 * (pm.blk_off[pblock + 1] - sh0);
     for (int j = tid; j < n_sh3; j += nt) {
       const int q = sh0 + j / 3, c = j % 3;
-      peer_push(pm, q, c, acc[(pm.node[q] - bd.node_start) + c * fstride], seq);
+      const PeerPushRec r = pm.push_rec[q];
+      peer_push(pm, r, q, c, acc[(r.info & 0xffff) + c * fstride], seq);
     }
   }
   const int n_early3 = 3 * bd.n_early;
@@ -525,13 +538,17 @@ __global__ void __launch_bounds__(SAA_LB) fused_step_kernel(DeviceMesh m, const 
   if (PEER) {
     for (int j = tid; j < n_sh3; j += nt) {
       const int q = sh0 + j / 3, c = j % 3;
-      const int node = pm.node[q], n = node - bd.node_start;
-      const double f = peer_collect(pm, q, c, acc[n + c * fstride], seq);
+      const PeerRecvRec r = pm.recv_rec[q];
+      const int n = pm.push_rec[q].info & 0xffff, node = bd.node_start + n;
       const int64_t g = 3 * (int64_t)node + c;
-      double v = cd_update_dof(f, m.fext[g], m.mass[g], rec[6 * n + 3 + c], dn[g], k);  // Dynamic_solver.py:26-32
-      if (m.tag[node] & (1 << c)) v = 0.0;
+      // operands first: their latency overlaps the poll
+      const double fe = m.fext[g], ma = m.mass[g], dnv = dn[g];
+      const int32_t tag = m.tag[node];
+      const double f = peer_collect(pm, r, q, c, acc[n + c * fstride], seq);
+      double v = cd_update_dof(f, fe, ma, rec[6 * n + 3 + c], dnv, k);  // Dynamic_solver.py:26-32
+      if (tag & (1 << c)) v = 0.0;
       out[g] = v;
-      if (hist_row != nullptr) hist_row[3 * (int64_t)pm.sidx[q] + c] = v;  // Online_predictor.py:260
+      if (hist_row != nullptr) hist_row[3 * (int64_t)r.sidx + c] = v;  // Online_predictor.py:260
     }
   }
   if (ABLATE == 8) {  // stamps leave through a buffer of their own (passed in place of the history row)
@@ -545,21 +562,23 @@ __global__ void __launch_bounds__(SAA_LB) fused_step_kernel(DeviceMesh m, const 
 }
 
 template __global__ void fused_step_kernel<false>(DeviceMesh, const double *, const double *, double *,
-                                                   double *, const double *, double *, StepConsts, PeerMap, unsigned);
+                                                   double *, const double *, double *, StepConsts, const PeerMap *, unsigned);
 template __global__ void fused_step_kernel<true>(DeviceMesh, const double *, const double *, double *,
-                                                  double *, const double *, double *, StepConsts, PeerMap, unsigned);
+                                                  double *, const double *, double *, StepConsts, const PeerMap *, unsigned);
 template __global__ void fused_step_kernel<false, 0, true>(DeviceMesh, const double *, const double *, double *,
-                                                            double *, const double *, double *, StepConsts, PeerMap,
-                                                            unsigned);
+                                                            double *, const double *, double *, StepConsts,
+                                                            const PeerMap *, unsigned);
 
 // Attach-time proof of the peer path: one exchange of known values (own[3*q+c], node-sorted order) -> the sums
 // in the caller's shared order.
 __global__ void peer_selftest_kernel(PeerMap pm, const double *__restrict__ own, double *__restrict__ out,
                                      unsigned seq) {
   const int gtid = blockIdx.x * blockDim.x + threadIdx.x, gthreads = gridDim.x * blockDim.x;
-  for (int j = gtid; j < 3 * pm.n_shared; j += gthreads) peer_push(pm, j / 3, j % 3, own[j], seq);
-  for (int j = gtid; j < 3 * pm.n_shared; j += gthreads)
-    out[3 * (int64_t)pm.sidx[j / 3] + j % 3] = peer_collect(pm, j / 3, j % 3, own[j], seq);
+  for (int j = gtid; j < 3 * pm.n_shared; j += gthreads) peer_push(pm, pm.push_rec[j / 3], j / 3, j % 3, own[j], seq);
+  for (int j = gtid; j < 3 * pm.n_shared; j += gthreads) {
+    const PeerRecvRec r = pm.recv_rec[j / 3];
+    out[3 * (int64_t)r.sidx + j % 3] = peer_collect(pm, r, j / 3, j % 3, own[j], seq);
+  }
 }
 
 // After the all-reduce: shared nodes get the update from the summed force (Dynamic_solver.py:26-32),
@@ -641,14 +660,14 @@ void launch_fused_step(const DeviceMesh &m, int threads, int lds_bytes, hipStrea
                        const double *dn, double *d1, double *iface, const double *table_row, double *hist_row,
                        const StepConsts &k) {
   hipLaunchKernelGGL(fused_step_kernel<false>, dim3(m.n_blocks), dim3(threads), lds_bytes, st, m, d0, dn, d1,
-                     iface, table_row, hist_row, k, PeerMap{}, 0u);
+                     iface, table_row, hist_row, k, static_cast<const PeerMap *>(nullptr), 0u);
 }
 
 void launch_fused_step_peer(const DeviceMesh &m, int threads, int lds_bytes, hipStream_t st, const double *d0,
-                            const double *dn, double *d1, double *hist_row, const StepConsts &k, const PeerMap &pm,
-                            unsigned seq) {
+                            const double *dn, double *d1, double *hist_row, const StepConsts &k,
+                            const PeerMap *pm_dev, unsigned seq) {
   hipLaunchKernelGGL((fused_step_kernel<false, 0, true>), dim3(m.n_blocks), dim3(threads), lds_bytes, st, m, d0, dn,
-                     d1, static_cast<double *>(nullptr), static_cast<const double *>(nullptr), hist_row, k, pm, seq);
+                     d1, static_cast<double *>(nullptr), static_cast<const double *>(nullptr), hist_row, k, pm_dev, seq);
 }
 
 void launch_peer_selftest(const PeerMap &pm, hipStream_t st, const double *own, double *out, unsigned seq) {
@@ -667,7 +686,7 @@ void launch_fused_step_ablated(int variant, const DeviceMesh &m, int threads, in
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_step_kernel<false, V>),                \
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);                      \
     hipLaunchKernelGGL((fused_step_kernel<false, V>), dim3(m.n_blocks), dim3(threads), lds_bytes, st, m, d0, \
-                       dn, d1, none, cnone, V == 8 ? dbg : none, k, PeerMap{}, 0u);                        \
+                       dn, d1, none, cnone, V == 8 ? dbg : none, k, static_cast<const PeerMap *>(nullptr), 0u); \
     break;
   switch (variant) {
     SAA_ABL(0) SAA_ABL(1) SAA_ABL(2) SAA_ABL(3) SAA_ABL(4) SAA_ABL(5) SAA_ABL(6) SAA_ABL(7) SAA_ABL(8)
@@ -681,7 +700,7 @@ void launch_force_only(const DeviceMesh &m, int threads, int lds_bytes, hipStrea
   StepConsts k{};
   hipLaunchKernelGGL(fused_step_kernel<true>, dim3(m.n_blocks), dim3(threads), lds_bytes, st, m, d, d, f,
                      static_cast<double *>(nullptr), static_cast<const double *>(nullptr),
-                     static_cast<double *>(nullptr), k, PeerMap{}, 0u);
+                     static_cast<double *>(nullptr), k, static_cast<const PeerMap *>(nullptr), 0u);
 }
 
 void launch_iface_finish(const DeviceMesh &m, const SharedMap &sh, hipStream_t st, const double *d0,

@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Diagnostic: cost of the in-kernel peer exchange (push + collect phases of fused_step_kernel<PEER>) on ONE GPU.
+
+Takes the partition a middle rank holds in the driver's N-GPU bench (x-slab of the 25n x n x n beam, two
+interfaces), attaches it to imaginary neighbours living in its own inbox (saa_debug_peer_loopback) and times
+saa_step_peer against plain saa_step on the same partition.  Local memory latency stands in for xGMI's.
+
+    python tools/peer_loopback.py [--gpus 8] [--rank 3] [--steps 2000]
+"""
+import argparse
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from bench import ALPHA, E, GAMMA, N_FOR_GPUS, NU, RHO, FZ  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=8)
+    ap.add_argument("--rank", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--refine", type=int, default=0)
+    args = ap.parse_args()
+    import synchronization_avoiding_algorithms_amd as saa
+    from synchronization_avoiding_algorithms_amd import _lib, fem_setup as fs
+    from synchronization_avoiding_algorithms_amd.mesh import clamp_nodes, slab_partition, structured_beam
+
+    n = args.refine or N_FOR_GPUS[args.gpus]
+    mesh = structured_beam(n)
+    epart = slab_partition(mesh, args.gpus)
+    layouts, gshared = fs.build_layouts(mesh.tets, epart, args.gpus, len(mesh.points), clamp_nodes(mesh))
+    lay = layouts[args.rank]
+    lumped, fpre = fs.lumped_mass_and_load(mesh.points, mesh.tets, RHO, FZ)
+    dt = fs.cfl_dt(mesh.points, mesh.tets, E, NU, RHO, GAMMA)
+    lmd, mu = fs.lame(E, NU)
+
+    def make():
+        return saa.HipExplicitSolver(mesh.points[lay.nodes], lay.cells_local, lumped[lay.local_dof],
+                                     fpre[lay.local_dof], lay.dirichlet_dofs, lmd, mu, dt, ALPHA,
+                                     shared_local=lay.shared_local, shared_slots=lay.shared_slots,
+                                     n_global_shared=len(gshared))
+
+    lib = _lib.load()
+    for name in ("saa_debug_peer_loopback", "saa_debug_time_peer"):
+        getattr(lib, name).restype = C.c_int
+    print(f"rank {args.rank} of {args.gpus}: {len(lay.cells_local)} tets, {len(lay.nodes)} nodes, "
+          f"{len(lay.shared_local)} shared nodes", flush=True)
+    plain = make()
+    plain.step(200)
+    base = plain.time_steps(args.steps) / args.steps * 1e3
+    print(f"plain step (no exchange)        : {base:7.2f} us/step   plan {plain.plan_stats()}", flush=True)
+    plain.close()
+    for world in (2, 3):
+        sol = make()
+        _lib.check(lib.saa_debug_peer_loopback(sol._h, C.c_int32(world)))
+        ms = C.c_double()
+        _lib.check(lib.saa_debug_time_peer(sol._h, C.c_int32(200), C.byref(ms)))
+        _lib.check(lib.saa_debug_time_peer(sol._h, C.c_int32(args.steps), C.byref(ms)))
+        us = ms.value / args.steps * 1e3
+        print(f"peer step, {world - 1} loopback neighbour(s): {us:7.2f} us/step   (+{us - base:.2f} us)", flush=True)
+        sol.close()
+
+
+if __name__ == "__main__":
+    main()
