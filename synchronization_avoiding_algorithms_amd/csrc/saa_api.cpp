@@ -118,6 +118,12 @@ struct saa_solver {
   std::vector<double> host_tmp;
   void *comm = nullptr;  // ncclComm_t of the native exchange (saa_comm_init)
   int32_t comm_world = 0;
+  // resident multi-step kernel (saa_device.h: PersistArgs)
+  DevBuf<int32_t> ps_err;
+  DevBuf<saa::PeerEntry> ps_entries;  // 2 x 3*n_nodes stamped displacements
+  DevBuf<saa::PersistArgs> ps_args;   // argument block of the launch in flight
+  int32_t ps_lds = 0, ps_max_items = 0, ps_steps = 0;
+  bool ps_capable = false;  // plan fits LDS and all workgroups can be co-resident
   // direct peer exchange (saa_peer_export / saa_peer_attach)
   void *peer_mem = nullptr;          // this rank's exported allocation: flags + inbox (fine-grained)
   int32_t peer_world = 0;
@@ -147,6 +153,7 @@ struct saa_solver {
     sh_slot.release(); sh_foreign.release(); slot_sidx.release(); conn.release(); xyz.release(); mass.release(); fext.release(); mass_node.release(); fext_yz.release();
     for (auto &b : dbuf) b.release();
     for (auto &b : scratch) b.release();
+    ps_entries.release(); ps_err.release(); ps_args.release();
     for (void *q : peer_open) (void)hipIpcCloseMemHandle(q);
     peer_open.clear();
     if (peer_mem) (void)hipFree(peer_mem);
@@ -284,6 +291,86 @@ int check_peer_error(saa_solver *s) {
   int32_t e = 0;
   HIP_TRY(hipMemcpy(&e, s->px_err.p, sizeof(e), hipMemcpyDeviceToHost));
   if (e != 0) return fail(SAA_E_STATE, "peer exchange: timed out waiting for a neighbour rank's shared-node forces");
+  return SAA_OK;
+}
+
+// Steps shorter than this use one launch per step (the resident kernel pays its set-up once per launch).
+constexpr int32_t kPersistMinSteps = 8;
+
+int check_persist_error(saa_solver *s) {
+  if (!s->ps_capable) return SAA_OK;
+  int32_t e = 0;
+  HIP_TRY(hipMemcpy(&e, s->ps_err.p, sizeof(e), hipMemcpyDeviceToHost));
+  if (e != 0) return fail(SAA_E_STATE, "resident step kernel: timed out waiting for a neighbouring workgroup");
+  return SAA_OK;
+}
+
+// Entry buffers and capacity check of the resident kernel; failure only disables it.
+void setup_persistent(saa_solver *s) {
+  s->ps_capable = false;
+  if (const char *env = std::getenv("SAA_NO_PERSISTENT"))
+    if (env[0] == '1') return;
+  const saa::Plan &plan = s->plan;
+  const int32_t nb = static_cast<int32_t>(plan.blocks.size());
+  int32_t max_items = 1;
+  for (const auto &b : plan.blocks) max_items = std::max(max_items, b.n_elem);
+  const int lds = saa::persistent_lds_bytes(plan.max_local, plan.max_owned, max_items);
+  if (lds == 0 || saa::persistent_max_blocks(s->device, s->threads, lds) < nb) return;
+  const size_t n_entries = 2 * 3 * static_cast<size_t>(plan.n_nodes);
+  if (s->ps_entries.alloc(n_entries) != hipSuccess || s->ps_args.alloc(1) != hipSuccess || s->ps_err.upload(std::vector<int32_t>(1, 0)) != hipSuccess ||
+      hipMemset(s->ps_entries.p, 0, n_entries * sizeof(saa::PeerEntry)) != hipSuccess) {  // stamp 0 = never written
+    (void)hipGetLastError();
+    s->ps_entries.release();
+    return;
+  }
+  s->ps_lds = lds;
+  s->ps_max_items = max_items;
+  s->ps_steps = 0;
+  s->ps_capable = true;
+}
+
+// nsteps exchange-free steps in ONE cooperative launch; returns SAA_OK with *done = false when the resident kernel
+// does not apply (the caller then launches one fused kernel per step).
+int try_persistent_steps(saa_solver *s, int32_t nsteps, const double *table_dev, int64_t table_row0, double *hist_dev,
+                         int64_t hist_row0, bool *done) {
+  *done = false;
+  if (!s->ps_capable || nsteps < kPersistMinSteps || !s->mesh.mass_node || !s->mesh.fext_yz) return SAA_OK;
+  saa::PersistArgs a{};
+  a.g0 = s->dbuf[s->i0].p;
+  a.g1 = s->dbuf[s->in_].p;
+  a.entries = s->ps_entries.p;
+  a.entry_stride = 3 * static_cast<int64_t>(s->plan.n_nodes);
+  if (static_cast<uint32_t>(s->ps_steps) > 0x7fff0000u) {  // stamps about to wrap: start over (0 = never written)
+    HIP_TRY(hipMemsetAsync(s->ps_entries.p, 0, s->ps_entries.n * sizeof(saa::PeerEntry), s->stream));
+    s->ps_steps = 0;
+  }
+  a.step_base = s->ps_steps;
+  a.nsteps = nsteps;
+  a.tn0 = s->tn;
+  a.ramp_on = s->ramp;
+  a.max_items = s->ps_max_items;
+  a.table = table_dev;
+  a.hist = hist_dev;
+  a.table_row0 = table_row0;
+  a.hist_row0 = hist_row0;
+  a.width = 3 * static_cast<int64_t>(s->n_shared);
+  a.err = s->ps_err.p;
+  double timeout_s = 30.0;
+  if (const char *env = std::getenv("SAA_PEER_TIMEOUT_S")) timeout_s = std::max(0.01, std::atof(env));
+  a.timeout_ticks = static_cast<int64_t>(timeout_s * 1e8);
+  // stream-ordered copy from pageable memory: staged before the call returns, lands before the kernel starts
+  HIP_TRY(hipMemcpyAsync(s->ps_args.p, &a, sizeof(a), hipMemcpyHostToDevice, s->stream));
+  const hipError_t e = saa::launch_persistent_steps(s->mesh, s->threads, s->ps_lds, s->stream, s->consts, s->ps_args.p,
+                                                    table_dev != nullptr);
+  if (e != hipSuccess) {  // e.g. the device cannot hold all workgroups right now: keep the per-step path
+    (void)hipGetLastError();
+    s->ps_capable = false;
+    return SAA_OK;
+  }
+  s->ps_steps = static_cast<int32_t>(static_cast<uint32_t>(s->ps_steps) + static_cast<uint32_t>(nsteps));
+  if (nsteps & 1) std::swap(s->i0, s->in_);
+  for (int32_t k = 0; k < nsteps; ++k) s->tn = s->tn + s->consts.dt;  // the kernel advanced its copy the same way
+  *done = true;
   return SAA_OK;
 }
 
@@ -467,6 +554,7 @@ int saa_create(const saa_problem *pb, saa_solver **out) {
   s->consts.alpha = pb->alpha;
   s->consts.half_alpha = 0.5 * pb->alpha;
   s->tn = 0.0;
+  setup_persistent(s);
   *out = s;
   return SAA_OK;
 }
@@ -507,6 +595,7 @@ int saa_get_state(saa_solver *s, double *d0_host, double *dn_host, double *tn) {
   if (!s) return fail(SAA_E_ARG, "saa_get_state: null handle");
   HIP_TRY(hipSetDevice(s->device));
   HIP_TRY(hipStreamSynchronize(s->stream));
+  if (int rc = check_persist_error(s)) return rc;
   if (int rc = check_peer_error(s)) return rc;
   if (d0_host)
     if (int rc = download_permuted(s, s->dbuf[s->i0].p, d0_host)) return rc;
@@ -570,6 +659,9 @@ int saa_step(saa_solver *s, int32_t nsteps) {
   if (!s || nsteps < 0) return fail(SAA_E_ARG, "saa_step: bad argument");
   if (s->pending) return fail(SAA_E_STATE, "saa_step: a synchronised step is in flight");
   HIP_TRY(hipSetDevice(s->device));
+  bool done = false;
+  if (int rc = try_persistent_steps(s, nsteps, nullptr, 0, nullptr, 0, &done)) return rc;
+  if (done) return check_launch();
   for (int32_t k = 0; k < nsteps; ++k) {
     s->set_ramp();
     saa::launch_fused_step(s->mesh, s->threads, s->lds_bytes, s->stream, s->dbuf[s->i0].p, s->dbuf[s->in_].p,
@@ -942,6 +1034,11 @@ int saa_step_predicted(saa_solver *s, int32_t nsteps, const double *table_dev, i
   if (s->pending) return fail(SAA_E_STATE, "saa_step_predicted: a synchronised step is in flight");
   HIP_TRY(hipSetDevice(s->device));
   const int64_t width = 3 * static_cast<int64_t>(s->n_shared);
+  bool done = false;
+  if (int rc = try_persistent_steps(s, nsteps, s->n_shared > 0 ? table_dev : nullptr, table_row0,
+                                    s->n_shared > 0 ? hist_dev : nullptr, hist_row0, &done))
+    return rc;
+  if (done) return check_launch();
   for (int32_t k = 0; k < nsteps; ++k) {
     s->set_ramp();
     // halo overwrite + history record are fused into the step kernel's epilogue (one launch per step)
@@ -972,6 +1069,7 @@ int saa_synchronize(saa_solver *s) {
   if (!s) return fail(SAA_E_ARG, "saa_synchronize: null handle");
   HIP_TRY(hipSetDevice(s->device));
   HIP_TRY(hipStreamSynchronize(s->stream));
+  if (int rc = check_persist_error(s)) return rc;
   return check_peer_error(s);
 }
 

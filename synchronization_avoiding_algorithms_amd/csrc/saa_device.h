@@ -87,6 +87,32 @@ void launch_fused_step_peer(const DeviceMesh &m, int threads, int lds_bytes, hip
                             const double *dn, double *d1, double *hist_row, const StepConsts &k,
                             const PeerMap *pm_dev, unsigned seq);
 void launch_peer_selftest(const PeerMap &pm, hipStream_t st, const double *own, double *out, unsigned seq);
+// Resident multi-step kernel (persistent_steps_kernel): ONE cooperative launch advances the partition by many time
+// steps.  Everything static (coordinates, mass, load, tags, connectivity) and the block's own displacements d^n,
+// d^(n-1) stay in LDS between steps; per step a workgroup only publishes its new displacements and re-reads those of
+// its halo nodes, as self-validating stamped entries (PeerEntry) - no flags, no grid barrier.
+struct PersistArgs {
+  double *g0, *g1;          // at launch g0 = d^n, g1 = d^(n-1) (internal order); step s writes d^(n+s+1) alternately
+  PeerEntry *entries;       // 2 x entry_stride stamped displacements (parity of the step count selects the half)
+  int64_t entry_stride;     // 3 * n_nodes
+  int32_t step_base;        // steps taken by earlier launches of this kernel (stamps continue from it)
+  int32_t nsteps;
+  double tn0;               // time of d^n at launch
+  int32_t ramp_on;          // linear_ramp (commons.py:7-11) on / off
+  int32_t max_items;        // LDS capacity for work items
+  const double *table;      // predicted phase (row = table_row0 + step), or nullptr
+  double *hist;             // history rows (hist_row0 + step), or nullptr
+  int64_t table_row0, hist_row0, width;  // width = 3 * n_shared
+  int32_t *err;             // set to 1 when a wait timed out
+  int64_t timeout_ticks;
+};
+// LDS bytes the resident kernel needs for this plan (0 = it cannot hold it).
+int persistent_lds_bytes(int max_local, int max_owned, int max_items);
+// How many workgroups of the resident kernel can be co-resident on the device (0 on error).
+int persistent_max_blocks(int device, int threads, int lds_bytes);
+hipError_t launch_persistent_steps(const DeviceMesh &m, int threads, int lds_bytes, hipStream_t st, const StepConsts &k,
+                                   const PersistArgs *args_dev, bool predict);
+
 hipError_t configure_kernels(int lds_bytes);
 void launch_fused_step(const DeviceMesh &m, int threads, int lds_bytes, hipStream_t st, const double *d0,
                        const double *dn, double *d1, double *iface, const double *table_row, double *hist_row,

@@ -581,6 +581,193 @@ __global__ void peer_selftest_kernel(PeerMap pm, const double *__restrict__ own,
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Resident multi-step kernel.  Same arithmetic as fused_step_kernel (item_forces, cd_update_dof), different data
+// flow: the workgroup keeps its block in LDS for the whole launch,
+//   rec   [max_local][6]  x y z ux uy uz   (x static; u of owned nodes updated in place, u of halo nodes re-read)
+//   acc   3 force planes,  dnl [3*max_owned] d^(n-1) of the owned dofs,
+//   massl / fextl [max_owned] nodal mass and (0,v,v) load,  tagl [max_owned],  connl [max_items] work items,
+// so that per step only 24 B per owned node leave the CU (new displacements) and 24 B per halo node enter it.
+// Step s of a block needs d^(n+s) of its halo nodes, written by their owners at the end of step s-1.  No flags, no
+// grid barrier: every published value is a 16-byte entry of two words, each = 32 bits of the double + the 32-bit
+// step count (the protocol of the peer exchange above), so a reader can load speculatively - after its first
+// interior sweep, consumed after the rest of the interior items - and recognise a value that has not arrived yet.
+// Two entry buffers alternate by step parity: an owner cannot overwrite what a reader still needs, because it cannot
+// get two steps ahead of a block it reads from.
+// All workgroups must be co-resident (cooperative launch); every wait is bounded (PersistArgs::timeout_ticks).
+// ---------------------------------------------------------------------------------------------
+// Cross-workgroup traffic of the resident kernel uses agent-scope relaxed atomics only (global_load/store ... sc1:
+// served by / written through to the level all XCDs share) plus execution barriers and vmcnt waits - no L2
+// write-back or invalidate inside the step loop (an acquire in a polling loop would invalidate the XCD's L2 on
+// every iteration).
+__device__ __forceinline__ void store_agent(double *p, double v) {
+  __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v),
+                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double load_agent(const double *p) {
+  return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(p),
+                                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+
+__host__ __device__ inline int persist_off_dn(int max_local, int fstride) { return 6 * max_local + 3 * fstride; }
+
+// PREDICT: the predicted phase (table / history rows); a separate instantiation keeps its pointers out of the plain
+// kernel's scalar registers.  The argument block is read from device memory where it is needed for the same reason.
+#ifndef SAA_PERSIST_PRE
+#define SAA_PERSIST_PRE 2
+#endif
+constexpr int kPH = SAA_PERSIST_PRE;  // stamped halo entries per thread in flight across the interior items
+template <bool PREDICT>
+__global__ void __launch_bounds__(SAA_LB) persistent_steps_kernel(DeviceMesh m, StepConsts k,
+                                                                  const PersistArgs *__restrict__ ap) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  struct {
+    double *g0, *g1;
+    PeerEntry *entries;
+    int64_t entry_stride;
+    int32_t step_base, nsteps, ramp_on, max_items;
+    double tn0;
+  } a = {ap->g0, ap->g1, ap->entries, ap->entry_stride, ap->step_base, ap->nsteps, ap->ramp_on, ap->max_items, ap->tn0};
+  const int pblock = plan_block(blockIdx.x, m.n_blocks);
+  const BlockDesc bd = m.blocks[pblock];
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int fstride = m.force_stride;
+  double *rec = lds;
+  double *acc = lds + 6 * m.max_local;
+  double *dnl = lds + persist_off_dn(m.max_local, fstride);
+  double *massl = dnl + 3 * m.max_owned;
+  double *fextl = massl + m.max_owned;
+  uint2 *connl = reinterpret_cast<uint2 *>(fextl + m.max_owned);
+  int32_t *tagl = reinterpret_cast<int32_t *>(connl + a.max_items);
+  const int n_own3 = 3 * bd.n_owned, n_halo3 = 3 * bd.n_halo;
+  const int64_t base = 3 * (int64_t)bd.node_start;
+  const int32_t *hid = m.halo_ids + bd.halo_off;
+
+  // ---- once: the block's image (halo displacements of the first step included) -----------------------
+  for (int i = tid; i < n_own3; i += nt) {
+    const int n = i / 3, c = i - 3 * n;
+    rec[6 * n + c] = m.xyz[base + i];
+    rec[6 * n + 3 + c] = a.g0[base + i];
+    dnl[i] = a.g1[base + i];
+    acc[n + c * fstride] = 0.0;
+  }
+  for (int n = tid; n < bd.n_owned; n += nt) {
+    massl[n] = m.mass_node[bd.node_start + n];
+    fextl[n] = m.fext_yz[bd.node_start + n];
+    tagl[n] = m.tag[bd.node_start + n];
+  }
+  for (int i = tid; i < n_halo3; i += nt) {
+    const int n = i / 3, c = i - 3 * n;
+    const int64_t g = 3 * (int64_t)hid[n] + c;
+    rec[6 * (bd.n_owned + n) + c] = m.xyz[g];
+    rec[6 * (bd.n_owned + n) + 3 + c] = a.g0[g];
+  }
+  for (int e = tid; e < bd.n_elem; e += nt) connl[e] = m.conn[bd.elem_off + e];
+  __syncthreads();
+
+  // boundary sweep starts at the wave after the last interior chunk (see fused_step_kernel)
+  const int shift = (((bd.n_interior + 63) >> 6) % (nt >> 6)) << 6;
+  const int e_b0 = bd.n_interior + (tid >= shift ? tid - shift : tid - shift + nt);
+  const int last = max(bd.n_elem - 1, 0);
+  double tn = a.tn0;
+  double sink = 0.0;
+  for (int s = 0; s < a.nsteps; ++s) {
+    k.ramp = a.ramp_on ? (tn <= 1 ? tn : 1.0) : 1.0;  // commons.py:7-11 at the time of d^n
+    const unsigned want = (unsigned)(a.step_base + s);  // stamp of d^(n+s), written by its owner in step s-1
+    const PeerEntry *ein = a.entries + (int64_t)(s & 1) * a.entry_stride;
+    // ---- 1. first interior sweep: by its end the neighbours' displacements have landed -----------------
+    if (tid < bd.n_interior) item_forces<0>(connl[tid], rec, acc, fstride, bd.n_owned, m.lambda_, m.mu, tid, sink);
+    // ---- 2. halo displacements: in flight while the remaining interior items run ----------------------
+    unsigned long long hlo[kPH], hhi[kPH];
+    if (s > 0) {
+#pragma unroll
+      for (int j = 0; j < kPH; ++j) {
+        const int i = min(tid + j * nt, max(n_halo3 - 1, 0));
+        const int n = i / 3;
+        const PeerEntry *e = ein + 3 * (int64_t)hid[n] + (i - 3 * n);
+        hlo[j] = __hip_atomic_load(&e->lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        hhi[j] = __hip_atomic_load(&e->hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    for (int e = tid + nt; e < bd.n_interior; e += nt)
+      item_forces<0>(connl[e], rec, acc, fstride, bd.n_owned, m.lambda_, m.mu, tid, sink);
+    // ---- 3. halo displacements -> LDS (an entry still carrying an older stamp is simply read again) ------
+    if (s > 0) {
+      // (the entry address is recomputed on the rare retry path: keeping it live would cost registers in the
+      // interior loop above)
+      auto settle = [&](int i, unsigned long long lo, unsigned long long hi) {
+        if ((unsigned)(lo >> 32) != want || (unsigned)(hi >> 32) != want) {
+          const int n = i / 3;
+          const PeerEntry *e = ein + 3 * (int64_t)hid[n] + (i - 3 * n);
+          const long long t0 = wall_clock64();
+          do {
+            if (wall_clock64() - t0 > *(volatile const int64_t *)&ap->timeout_ticks) {
+              // workgroups not co-resident, or a fault elsewhere: report, do not hang
+              __hip_atomic_store(*(int32_t *volatile const *)&ap->err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+              break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+            lo = __hip_atomic_load(&e->lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            hi = __hip_atomic_load(&e->hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          } while ((unsigned)(lo >> 32) != want || (unsigned)(hi >> 32) != want);
+        }
+        return __longlong_as_double((long long)((hi << 32) | (lo & 0xffffffffull)));
+      };
+#pragma unroll
+      for (int j = 0; j < kPH; ++j) {
+        const int i = tid + j * nt;
+        if (i < n_halo3) {
+          const int n = i / 3, c = i - 3 * n;
+          rec[6 * (bd.n_owned + n) + 3 + c] = settle(i, hlo[j], hhi[j]);
+        }
+      }
+      for (int i = tid + kPH * nt; i < n_halo3; i += nt) {
+        const int n = i / 3, c = i - 3 * n;
+        rec[6 * (bd.n_owned + n) + 3 + c] = settle(i, 0ull, 0ull);  // stamp 0 never matches: loads on the retry path
+      }
+    }
+    lds_barrier();
+    // ---- 4. boundary items ----------------------------------------------------------------------------
+    if (e_b0 < bd.n_elem) {
+      uint2 cur = connl[e_b0];
+      for (int e = e_b0; e < bd.n_elem; e += nt) {
+        const uint2 nxt = connl[min(e + nt, last)];
+        item_forces<0>(cur, rec, acc, fstride, bd.n_owned, m.lambda_, m.mu, tid, sink);
+        cur = nxt;
+      }
+    }
+    lds_barrier();
+    // ---- 5. update of the owned dofs: LDS operands; the new value leaves as a plain double (state) and as a
+    //         stamped entry (what the neighbouring workgroups read in the next step) ------------------------
+    double *gnext = (s & 1) ? a.g0 : a.g1;
+    PeerEntry *eout = a.entries + (int64_t)((s + 1) & 1) * a.entry_stride + base;
+    const unsigned long long stamp = (unsigned long long)(unsigned)(a.step_base + s + 1) << 32;
+    for (int i = tid; i < n_own3; i += nt) {
+      const int n = i / 3, c = i - 3 * n;
+      const double u = rec[6 * n + 3 + c];
+      const int32_t tag = tagl[n];
+      double v = cd_update_dof(acc[n + c * fstride], c == 0 ? 0.0 : fextl[n], massl[n], u, dnl[i], k);
+      if (tag & (1 << c)) v = 0.0;  // d1[Local_Dirichlet] = 0   (Dynamic_solver.py:20)
+      if (PREDICT && (tag & kTagShared)) {
+        // predicted phase: d1[loc_dof_shared] = prediction, recorded as history (Online_predictor.py:298,301)
+        const int64_t j = 3 * (int64_t)m.slot_sidx[tag >> kTagSlotShift] + c, w = ap->width;
+        v = ap->table[(ap->table_row0 + s) * w + j];
+        if (ap->hist != nullptr) ap->hist[(ap->hist_row0 + s) * w + j] = v;
+      }
+      gnext[base + i] = v;
+      const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+      __hip_atomic_store(&eout[i].lo, stamp | (b & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&eout[i].hi, stamp | (b >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      dnl[i] = u;
+      rec[6 * n + 3 + c] = v;
+      acc[n + c * fstride] = 0.0;
+    }
+    tn = tn + k.dt;  // Data_prepare.py:235
+    lds_barrier();
+  }
+  if (sink == 12345.678) acc[0] = sink;
+}
+
 // After the all-reduce: shared nodes get the update from the summed force (Dynamic_solver.py:26-32),
 // optional history record (Online_predictor.py:260); slots of shared nodes this rank does not hold
 // are zeroed so that the next all-reduce sees only fresh partial forces.
@@ -693,6 +880,40 @@ void launch_fused_step_ablated(int variant, const DeviceMesh &m, int threads, in
     default: break;
   }
 #undef SAA_ABL
+}
+
+int persistent_lds_bytes(int max_local, int max_owned, int max_items) {
+  const int fstride = force_stride_for(max_owned);
+  const long long bytes = 8ll * (persist_off_dn(max_local, fstride) + 3 * max_owned + 2 * max_owned) + 8ll * max_items +
+                          4ll * max_owned + 16;
+  return bytes <= 160 * 1024 ? (int)((bytes + 15) / 16 * 16) : 0;
+}
+
+int persistent_max_blocks(int device, int threads, int lds_bytes) {
+  int per_cu = 0, cus = 0;
+  if (hipFuncSetAttribute(reinterpret_cast<const void *>(&persistent_steps_kernel<false>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess ||
+      hipFuncSetAttribute(reinterpret_cast<const void *>(&persistent_steps_kernel<true>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess)
+    return 0;
+  int per_cu_p = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, persistent_steps_kernel<false>, threads, lds_bytes) != hipSuccess ||
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_p, persistent_steps_kernel<true>, threads, lds_bytes) != hipSuccess)
+    return 0;
+  per_cu = per_cu < per_cu_p ? per_cu : per_cu_p;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) return 0;
+  return per_cu * cus;
+}
+
+hipError_t launch_persistent_steps(const DeviceMesh &m, int threads, int lds_bytes, hipStream_t st, const StepConsts &k,
+                                   const PersistArgs *args_dev, bool predict) {
+  DeviceMesh mm = m;
+  StepConsts kk = k;
+  const PersistArgs *ap = args_dev;
+  void *args[] = {&mm, &kk, &ap};
+  const void *fn = predict ? reinterpret_cast<const void *>(&persistent_steps_kernel<true>)
+                           : reinterpret_cast<const void *>(&persistent_steps_kernel<false>);
+  return hipLaunchCooperativeKernel(fn, dim3(m.n_blocks), dim3(threads), args, lds_bytes, st);
 }
 
 void launch_force_only(const DeviceMesh &m, int threads, int lds_bytes, hipStream_t st, const double *d,

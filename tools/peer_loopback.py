@@ -25,6 +25,9 @@ def main():
     ap.add_argument("--rank", type=int, default=3)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--refine", type=int, default=0)
+    ap.add_argument("--block-nodes", type=int, default=0)
+    ap.add_argument("--threads", type=int, default=0)
+    ap.add_argument("--plain-only", action="store_true")
     args = ap.parse_args()
     import synchronization_avoiding_algorithms_amd as saa
     from synchronization_avoiding_algorithms_amd import _lib, fem_setup as fs
@@ -43,7 +46,8 @@ def main():
         return saa.HipExplicitSolver(mesh.points[lay.nodes], lay.cells_local, lumped[lay.local_dof],
                                      fpre[lay.local_dof], lay.dirichlet_dofs, lmd, mu, dt, ALPHA,
                                      shared_local=lay.shared_local, shared_slots=lay.shared_slots,
-                                     n_global_shared=len(gshared))
+                                     n_global_shared=len(gshared), block_nodes=args.block_nodes,
+                                     threads=args.threads)
 
     lib = _lib.load()
     for name in ("saa_debug_peer_loopback", "saa_debug_time_peer"):
@@ -55,7 +59,7 @@ def main():
     base = plain.time_steps(args.steps) / args.steps * 1e3
     print(f"plain step (no exchange)        : {base:7.2f} us/step   plan {plain.plan_stats()}", flush=True)
     plain.close()
-    for world in (2, 3):
+    for world in (() if args.plain_only else (2, 3)):
         sol = make()
         _lib.check(lib.saa_debug_peer_loopback(sol._h, C.c_int32(world)))
         ms = C.c_double()
