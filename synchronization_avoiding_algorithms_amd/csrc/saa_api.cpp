@@ -312,9 +312,12 @@ void setup_persistent(saa_solver *s) {
     if (env[0] == '1') return;
   const saa::Plan &plan = s->plan;
   const int32_t nb = static_cast<int32_t>(plan.blocks.size());
-  int32_t max_items = 1;
-  for (const auto &b : plan.blocks) max_items = std::max(max_items, b.n_elem);
-  const int lds = saa::persistent_lds_bytes(plan.max_local, plan.max_owned, max_items);
+  int32_t max_items = 1, max_halo = 1;
+  for (const auto &b : plan.blocks) {
+    max_items = std::max(max_items, b.n_elem);
+    max_halo = std::max(max_halo, b.n_halo);
+  }
+  const int lds = saa::persistent_lds_bytes(plan.max_local, plan.max_owned, max_items, max_halo);
   if (lds == 0 || saa::persistent_max_blocks(s->device, s->threads, lds) < nb) return;
   const size_t n_entries = 2 * 3 * static_cast<size_t>(plan.n_nodes);
   if (s->ps_entries.alloc(n_entries) != hipSuccess || s->ps_args.alloc(1) != hipSuccess || s->ps_err.upload(std::vector<int32_t>(1, 0)) != hipSuccess ||
@@ -1036,7 +1039,7 @@ int saa_step_predicted(saa_solver *s, int32_t nsteps, const double *table_dev, i
   const int64_t width = 3 * static_cast<int64_t>(s->n_shared);
   bool done = false;
   if (int rc = try_persistent_steps(s, nsteps, s->n_shared > 0 ? table_dev : nullptr, table_row0,
-                                    s->n_shared > 0 ? hist_dev : nullptr, hist_row0, &done))
+                                    hist_dev, hist_row0, &done))
     return rc;
   if (done) return check_launch();
   for (int32_t k = 0; k < nsteps; ++k) {

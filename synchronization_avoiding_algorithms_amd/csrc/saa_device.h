@@ -107,7 +107,7 @@ struct PersistArgs {
   int64_t timeout_ticks;
 };
 // LDS bytes the resident kernel needs for this plan (0 = it cannot hold it).
-int persistent_lds_bytes(int max_local, int max_owned, int max_items);
+int persistent_lds_bytes(int max_local, int max_owned, int max_items, int max_halo);
 // How many workgroups of the resident kernel can be co-resident on the device (0 on error).
 int persistent_max_blocks(int device, int threads, int lds_bytes);
 hipError_t launch_persistent_steps(const DeviceMesh &m, int threads, int lds_bytes, hipStream_t st, const StepConsts &k,

@@ -639,6 +639,7 @@ __global__ void __launch_bounds__(SAA_LB) persistent_steps_kernel(DeviceMesh m, 
   double *fextl = massl + m.max_owned;
   uint2 *connl = reinterpret_cast<uint2 *>(fextl + m.max_owned);
   int32_t *tagl = reinterpret_cast<int32_t *>(connl + a.max_items);
+  int32_t *hgl = tagl + m.max_owned;  // [3 * max_halo] entry index 3*node+c of every halo dof
   const int n_own3 = 3 * bd.n_owned, n_halo3 = 3 * bd.n_halo;
   const int64_t base = 3 * (int64_t)bd.node_start;
   const int32_t *hid = m.halo_ids + bd.halo_off;
@@ -661,7 +662,9 @@ __global__ void __launch_bounds__(SAA_LB) persistent_steps_kernel(DeviceMesh m, 
     const int64_t g = 3 * (int64_t)hid[n] + c;
     rec[6 * (bd.n_owned + n) + c] = m.xyz[g];
     rec[6 * (bd.n_owned + n) + 3 + c] = a.g0[g];
+    hgl[i] = (int32_t)g;
   }
+  if (tid == 0 && n_halo3 == 0) hgl[0] = 0;  // the clamped prefetch below reads index 0 even without a halo
   for (int e = tid; e < bd.n_elem; e += nt) connl[e] = m.conn[bd.elem_off + e];
   __syncthreads();
 
@@ -671,34 +674,44 @@ __global__ void __launch_bounds__(SAA_LB) persistent_steps_kernel(DeviceMesh m, 
   const int last = max(bd.n_elem - 1, 0);
   double tn = a.tn0;
   double sink = 0.0;
+#ifdef SAA_PERSIST_STAMPS
+  unsigned long long T[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tk = stamp();
+#define PSTAMP(j) { const unsigned long long t_ = stamp(); T[j] += t_ - tk; tk = t_; }
+#else
+#define PSTAMP(j)
+#endif
   for (int s = 0; s < a.nsteps; ++s) {
     k.ramp = a.ramp_on ? (tn <= 1 ? tn : 1.0) : 1.0;  // commons.py:7-11 at the time of d^n
+    // Opaque copy of the thread index for the halo and update phases: whatever is derived from it is recomputed
+    // every step.  Derived from `tid` the compiler hoists those per-thread constants (indices, addresses) out of
+    // the step loop, keeps them alive through the item loops and spills.
+    int ltid = tid;
+    asm volatile("" : "+v"(ltid));
     const unsigned want = (unsigned)(a.step_base + s);  // stamp of d^(n+s), written by its owner in step s-1
     const PeerEntry *ein = a.entries + (int64_t)(s & 1) * a.entry_stride;
     // ---- 1. first interior sweep: by its end the neighbours' displacements have landed -----------------
     if (tid < bd.n_interior) item_forces<0>(connl[tid], rec, acc, fstride, bd.n_owned, m.lambda_, m.mu, tid, sink);
+    PSTAMP(0)
     // ---- 2. halo displacements: in flight while the remaining interior items run ----------------------
     unsigned long long hlo[kPH], hhi[kPH];
     if (s > 0) {
 #pragma unroll
       for (int j = 0; j < kPH; ++j) {
-        const int i = min(tid + j * nt, max(n_halo3 - 1, 0));
-        const int n = i / 3;
-        const PeerEntry *e = ein + 3 * (int64_t)hid[n] + (i - 3 * n);
+        const PeerEntry *e = ein + hgl[min(ltid + j * nt, max(n_halo3 - 1, 0))];
         hlo[j] = __hip_atomic_load(&e->lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         hhi[j] = __hip_atomic_load(&e->hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
     for (int e = tid + nt; e < bd.n_interior; e += nt)
       item_forces<0>(connl[e], rec, acc, fstride, bd.n_owned, m.lambda_, m.mu, tid, sink);
+    PSTAMP(1)
     // ---- 3. halo displacements -> LDS (an entry still carrying an older stamp is simply read again) ------
     if (s > 0) {
       // (the entry address is recomputed on the rare retry path: keeping it live would cost registers in the
       // interior loop above)
       auto settle = [&](int i, unsigned long long lo, unsigned long long hi) {
         if ((unsigned)(lo >> 32) != want || (unsigned)(hi >> 32) != want) {
-          const int n = i / 3;
-          const PeerEntry *e = ein + 3 * (int64_t)hid[n] + (i - 3 * n);
+          const PeerEntry *e = ein + hgl[i];
           const long long t0 = wall_clock64();
           do {
             if (wall_clock64() - t0 > *(volatile const int64_t *)&ap->timeout_ticks) {
@@ -715,18 +728,20 @@ __global__ void __launch_bounds__(SAA_LB) persistent_steps_kernel(DeviceMesh m, 
       };
 #pragma unroll
       for (int j = 0; j < kPH; ++j) {
-        const int i = tid + j * nt;
+        const int i = ltid + j * nt;
         if (i < n_halo3) {
           const int n = i / 3, c = i - 3 * n;
           rec[6 * (bd.n_owned + n) + 3 + c] = settle(i, hlo[j], hhi[j]);
         }
       }
-      for (int i = tid + kPH * nt; i < n_halo3; i += nt) {
+      for (int i = ltid + kPH * nt; i < n_halo3; i += nt) {
         const int n = i / 3, c = i - 3 * n;
         rec[6 * (bd.n_owned + n) + 3 + c] = settle(i, 0ull, 0ull);  // stamp 0 never matches: loads on the retry path
       }
     }
+    PSTAMP(2)
     lds_barrier();
+    PSTAMP(3)
     // ---- 4. boundary items ----------------------------------------------------------------------------
     if (e_b0 < bd.n_elem) {
       uint2 cur = connl[e_b0];
@@ -736,13 +751,18 @@ __global__ void __launch_bounds__(SAA_LB) persistent_steps_kernel(DeviceMesh m, 
         cur = nxt;
       }
     }
+    PSTAMP(4)
     lds_barrier();
+    PSTAMP(5)
     // ---- 5. update of the owned dofs: LDS operands; the new value leaves as a plain double (state) and as a
     //         stamped entry (what the neighbouring workgroups read in the next step) ------------------------
     double *gnext = (s & 1) ? a.g0 : a.g1;
     PeerEntry *eout = a.entries + (int64_t)((s + 1) & 1) * a.entry_stride + base;
-    const unsigned long long stamp = (unsigned long long)(unsigned)(a.step_base + s + 1) << 32;
-    for (int i = tid; i < n_own3; i += nt) {
+    const unsigned stampw = (unsigned)(a.step_base + s + 1);
+    asm volatile("" : "+v"(ltid));
+    // the state buffers only need the last two steps of the launch (d^n and d^(n-1) for whoever comes next)
+    const bool keep = s + 2 >= a.nsteps;
+    for (int i = ltid; i < n_own3; i += nt) {
       const int n = i / 3, c = i - 3 * n;
       const double u = rec[6 * n + 3 + c];
       const int32_t tag = tagl[n];
@@ -754,17 +774,28 @@ __global__ void __launch_bounds__(SAA_LB) persistent_steps_kernel(DeviceMesh m, 
         v = ap->table[(ap->table_row0 + s) * w + j];
         if (ap->hist != nullptr) ap->hist[(ap->hist_row0 + s) * w + j] = v;
       }
-      gnext[base + i] = v;
-      const unsigned long long b = (unsigned long long)__double_as_longlong(v);
-      __hip_atomic_store(&eout[i].lo, stamp | (b & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(&eout[i].hi, stamp | (b >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (keep) gnext[base + i] = v;
+      {
+        // one 16-byte store, agent scope (write-through to the level all XCDs share); each half validates itself
+        const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+        const u32x4 w4 = {(unsigned)b, stampw, (unsigned)(b >> 32), stampw};
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(eout + i), "v"(w4) : "memory");
+      }
       dnl[i] = u;
       rec[6 * n + 3 + c] = v;
       acc[n + c * fstride] = 0.0;
     }
     tn = tn + k.dt;  // Data_prepare.py:235
+    PSTAMP(6)
     lds_barrier();
+    PSTAMP(7)
   }
+#ifdef SAA_PERSIST_STAMPS
+  if ((tid & 63) == 0 && ap->hist != nullptr) {  // diagnostic build: per-wave cycle totals leave through `hist`
+    unsigned long long *dbg = reinterpret_cast<unsigned long long *>(ap->hist) + 8 * ((size_t)blockIdx.x * (nt >> 6) + (tid >> 6));
+    for (int j = 0; j < 8; ++j) dbg[j] = T[j];
+  }
+#endif
   if (sink == 12345.678) acc[0] = sink;
 }
 
@@ -882,10 +913,10 @@ void launch_fused_step_ablated(int variant, const DeviceMesh &m, int threads, in
 #undef SAA_ABL
 }
 
-int persistent_lds_bytes(int max_local, int max_owned, int max_items) {
+int persistent_lds_bytes(int max_local, int max_owned, int max_items, int max_halo) {
   const int fstride = force_stride_for(max_owned);
   const long long bytes = 8ll * (persist_off_dn(max_local, fstride) + 3 * max_owned + 2 * max_owned) + 8ll * max_items +
-                          4ll * max_owned + 16;
+                          4ll * max_owned + 12ll * max_halo + 16;
   return bytes <= 160 * 1024 ? (int)((bytes + 15) / 16 * 16) : 0;
 }
 

@@ -549,6 +549,17 @@ bool build_once(int32_t n_nodes, int32_t n_elems, const double *xyz, const int32
     tot.atomic_cnt += st.atomic_cnt;
   }
   plan.lds_conflict_factor = tot.read_cnt ? tot.read_mult / tot.read_cnt : 1.0;
+  if (getenv("SAA_PLAN_DEBUG")) {
+    // distribution of the per-block work (items) and of its interior / boundary split
+    int32_t mn = INT32_MAX, mx = 0, mxi = 0, mxb = 0;
+    double sum = 0;
+    for (const auto &b : plan.blocks) {
+      mn = std::min(mn, b.n_elem); mx = std::max(mx, b.n_elem); sum += b.n_elem;
+      mxi = std::max(mxi, b.n_interior); mxb = std::max(mxb, b.n_elem - b.n_interior);
+    }
+    fprintf(stderr, "plan: items per block min %d mean %.1f max %d; max interior %d, max boundary %d\n", mn,
+            sum / plan.blocks.size(), mx, mxi, mxb);
+  }
   if (getenv("SAA_PLAN_DEBUG"))
     fprintf(stderr,
             "plan: %lld element copies in %lld items (%lld pairs); read conflict factor %.3f, atomic %.3f (%u threads)\n",

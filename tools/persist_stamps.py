@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Diagnostic: where a step of the resident kernel spends its cycles (build with -DSAA_PERSIST_STAMPS).
+
+    hipcc ... -DSAA_PERSIST_STAMPS -o tools/exp/libsaa_stamps.so ; SAA_LIB_PATH=tools/exp/libsaa_stamps.so python tools/persist_stamps.py
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import build_rank_solver  # noqa: E402
+from synchronization_avoiding_algorithms_amd.mesh import structured_beam  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 19
+steps = 1000
+mesh = structured_beam(n)
+sol, lay, _, _ = build_rank_solver(mesh, 1, 0, 0)
+st = sol.plan_stats()
+waves = st["n_blocks"] * st["threads"] // 64
+dbg = torch.zeros(8 * waves, dtype=torch.float64, device="cuda")  # reinterpreted as uint64 by the kernel
+# the stamped build writes through PersistArgs::hist: hand it over with a zero-width "table" (n_shared = 0)
+sol.step(200)
+sol.synchronize()
+import ctypes as C
+from synchronization_avoiding_algorithms_amd import _lib
+lib = _lib.load()
+_lib.check(lib.saa_step_predicted(sol._h, C.c_int32(steps), C.c_void_p(dbg.data_ptr()), C.c_int64(0),
+                                  C.c_void_p(dbg.data_ptr()), C.c_int64(0)))
+sol.synchronize()
+t = dbg.cpu().numpy().view(np.uint64).reshape(waves, 8).astype(np.float64) / steps
+names = ["interior sweep 1", "issue halo loads + interior rest", "settle halo -> LDS", "barrier (halo)",
+         "boundary items", "barrier (slowest wave)", "update", "barrier (end of step)"]
+tot = t.sum(axis=1)
+print(f"n={n} plan {st}")
+print(f"cycles per step per wave (100 MHz? no: shader clock), median total {np.median(tot):.0f}")
+for j, nm in enumerate(names):
+    print(f"  {nm:34s} median {np.median(t[:, j]):8.0f}  p90 {np.percentile(t[:, j], 90):8.0f}  max {t[:, j].max():8.0f}")
+ms = sol.time_steps(1000)
+print(f"stamped build: {ms:.3f} us/step")
