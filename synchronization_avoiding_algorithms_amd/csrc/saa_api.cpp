@@ -335,7 +335,7 @@ void setup_persistent(saa_solver *s) {
 // nsteps exchange-free steps in ONE cooperative launch; returns SAA_OK with *done = false when the resident kernel
 // does not apply (the caller then launches one fused kernel per step).
 int try_persistent_steps(saa_solver *s, int32_t nsteps, const double *table_dev, int64_t table_row0, double *hist_dev,
-                         int64_t hist_row0, bool *done) {
+                         int64_t hist_row0, bool *done, bool peer = false) {
   *done = false;
   if (!s->ps_capable || nsteps < kPersistMinSteps || !s->mesh.mass_node || !s->mesh.fext_yz) return SAA_OK;
   saa::PersistArgs a{};
@@ -361,10 +361,13 @@ int try_persistent_steps(saa_solver *s, int32_t nsteps, const double *table_dev,
   double timeout_s = 30.0;
   if (const char *env = std::getenv("SAA_PEER_TIMEOUT_S")) timeout_s = std::max(0.01, std::atof(env));
   a.timeout_ticks = static_cast<int64_t>(timeout_s * 1e8);
-  // stream-ordered copy from pageable memory: staged before the call returns, lands before the kernel starts
+  // (argument block: stream-ordered copy from pageable memory, staged before the call returns)
+  a.peer = peer ? s->px_map.p : nullptr;
+  a.peer_seq_base = s->peer_seq;
+  if (peer && s->peer_seq > 0xffffffffu - static_cast<uint32_t>(nsteps) - 2u) return SAA_OK;  // wrap: per-step path
   HIP_TRY(hipMemcpyAsync(s->ps_args.p, &a, sizeof(a), hipMemcpyHostToDevice, s->stream));
   const hipError_t e = saa::launch_persistent_steps(s->mesh, s->threads, s->ps_lds, s->stream, s->consts, s->ps_args.p,
-                                                    table_dev != nullptr);
+                                                    peer ? 2 : (table_dev != nullptr ? 1 : 0));
   if (e != hipSuccess) {  // e.g. the device cannot hold all workgroups right now: keep the per-step path
     (void)hipGetLastError();
     s->ps_capable = false;
@@ -373,6 +376,7 @@ int try_persistent_steps(saa_solver *s, int32_t nsteps, const double *table_dev,
   s->ps_steps = static_cast<int32_t>(static_cast<uint32_t>(s->ps_steps) + static_cast<uint32_t>(nsteps));
   if (nsteps & 1) std::swap(s->i0, s->in_);
   for (int32_t k = 0; k < nsteps; ++k) s->tn = s->tn + s->consts.dt;  // the kernel advanced its copy the same way
+  if (peer) s->peer_seq += static_cast<uint32_t>(nsteps);
   *done = true;
   return SAA_OK;
 }
@@ -1017,6 +1021,9 @@ int saa_step_peer(saa_solver *s, int32_t nsteps, double *hist_dev, int64_t hist_
   if (s->pending) return fail(SAA_E_STATE, "saa_step_peer: a synchronised step is in flight");
   HIP_TRY(hipSetDevice(s->device));
   const int64_t width = 3 * static_cast<int64_t>(s->n_shared);
+  bool done = false;
+  if (int rc = try_persistent_steps(s, nsteps, nullptr, 0, hist_dev, hist_row0, &done, true)) return rc;
+  if (done) return check_launch();
   for (int32_t k = 0; k < nsteps; ++k) {
     s->set_ramp();
     if (++s->peer_seq == 0) ++s->peer_seq;  // 0 marks "never written"

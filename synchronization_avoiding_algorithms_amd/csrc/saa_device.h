@@ -105,13 +105,15 @@ struct PersistArgs {
   int64_t table_row0, hist_row0, width;  // width = 3 * n_shared
   int32_t *err;             // set to 1 when a wait timed out
   int64_t timeout_ticks;
+  const PeerMap *peer;      // device copy of the peer map (synchronised steps with the peer exchange), or nullptr
+  uint32_t peer_seq_base;   // sequence number of the last exchange before this launch
 };
 // LDS bytes the resident kernel needs for this plan (0 = it cannot hold it).
 int persistent_lds_bytes(int max_local, int max_owned, int max_items, int max_halo);
 // How many workgroups of the resident kernel can be co-resident on the device (0 on error).
 int persistent_max_blocks(int device, int threads, int lds_bytes);
 hipError_t launch_persistent_steps(const DeviceMesh &m, int threads, int lds_bytes, hipStream_t st, const StepConsts &k,
-                                   const PersistArgs *args_dev, bool predict);
+                                   const PersistArgs *args_dev, int mode);
 
 hipError_t configure_kernels(int lds_bytes);
 void launch_fused_step(const DeviceMesh &m, int threads, int lds_bytes, hipStream_t st, const double *d0,

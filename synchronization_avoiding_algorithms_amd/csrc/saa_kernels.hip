@@ -617,7 +617,9 @@ __host__ __device__ inline int persist_off_dn(int max_local, int fstride) { retu
 #define SAA_PERSIST_PRE 2
 #endif
 constexpr int kPH = SAA_PERSIST_PRE;  // stamped halo entries per thread in flight across the interior items
-template <bool PREDICT>
+// PEER: synchronised steps with the direct peer exchange (shared nodes pushed to / collected from the neighbour
+// ranks inside the step loop, like fused_step_kernel<.., PEER>).
+template <bool PREDICT, bool PEER>
 __global__ void __launch_bounds__(SAA_LB) persistent_steps_kernel(DeviceMesh m, StepConsts k,
                                                                   const PersistArgs *__restrict__ ap) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -762,18 +764,8 @@ __global__ void __launch_bounds__(SAA_LB) persistent_steps_kernel(DeviceMesh m, 
     asm volatile("" : "+v"(ltid));
     // the state buffers only need the last two steps of the launch (d^n and d^(n-1) for whoever comes next)
     const bool keep = s + 2 >= a.nsteps;
-    for (int i = ltid; i < n_own3; i += nt) {
-      const int n = i / 3, c = i - 3 * n;
-      const double u = rec[6 * n + 3 + c];
-      const int32_t tag = tagl[n];
-      double v = cd_update_dof(acc[n + c * fstride], c == 0 ? 0.0 : fextl[n], massl[n], u, dnl[i], k);
-      if (tag & (1 << c)) v = 0.0;  // d1[Local_Dirichlet] = 0   (Dynamic_solver.py:20)
-      if (PREDICT && (tag & kTagShared)) {
-        // predicted phase: d1[loc_dof_shared] = prediction, recorded as history (Online_predictor.py:298,301)
-        const int64_t j = 3 * (int64_t)m.slot_sidx[tag >> kTagSlotShift] + c, w = ap->width;
-        v = ap->table[(ap->table_row0 + s) * w + j];
-        if (ap->hist != nullptr) ap->hist[(ap->hist_row0 + s) * w + j] = v;
-      }
+    // new value of owned dof i: state buffer, stamped entry for the neighbouring workgroups, LDS image
+    auto commit = [&](int i, int n, int c, double u, double v) {
       if (keep) gnext[base + i] = v;
       {
         // one 16-byte store, agent scope (write-through to the level all XCDs share); each half validates itself
@@ -784,6 +776,50 @@ __global__ void __launch_bounds__(SAA_LB) persistent_steps_kernel(DeviceMesh m, 
       dnl[i] = u;
       rec[6 * n + 3 + c] = v;
       acc[n + c * fstride] = 0.0;
+    };
+    // PEER: partial forces of this block's shared nodes leave for the neighbour ranks first; their values are
+    // collected after the update of the other nodes (the xGMI flight time hides under it)
+    int sh0 = 0, n_sh3 = 0;
+    unsigned pseq = 0;
+    PeerMap pm{};
+    if (PEER) {
+      pm = *ap->peer;
+      pseq = ap->peer_seq_base + (unsigned)s + 1u;  // the host keeps a launch clear of the wrap to 0 ("never written")
+      sh0 = pm.blk_off[pblock];
+      n_sh3 = 3 * (pm.blk_off[pblock + 1] - sh0);
+      for (int j = ltid; j < n_sh3; j += nt) {
+        const int q = sh0 + j / 3, c = j % 3;
+        const PeerPushRec r = pm.push_rec[q];
+        peer_push(pm, r, q, c, acc[(r.info & 0xffff) + c * fstride], pseq);
+      }
+    }
+    for (int i = ltid; i < n_own3; i += nt) {
+      const int n = i / 3, c = i - 3 * n;
+      const double u = rec[6 * n + 3 + c];
+      const int32_t tag = tagl[n];
+      if (PEER && (tag & kTagShared)) continue;  // below, from the force summed over the ranks
+      double v = cd_update_dof(acc[n + c * fstride], c == 0 ? 0.0 : fextl[n], massl[n], u, dnl[i], k);
+      if (tag & (1 << c)) v = 0.0;  // d1[Local_Dirichlet] = 0   (Dynamic_solver.py:20)
+      if (PREDICT && (tag & kTagShared)) {
+        // predicted phase: d1[loc_dof_shared] = prediction, recorded as history (Online_predictor.py:298,301)
+        const int64_t j = 3 * (int64_t)m.slot_sidx[tag >> kTagSlotShift] + c, w = ap->width;
+        v = ap->table[(ap->table_row0 + s) * w + j];
+        if (ap->hist != nullptr) ap->hist[(ap->hist_row0 + s) * w + j] = v;
+      }
+      commit(i, n, c, u, v);
+    }
+    if (PEER) {
+      for (int j = ltid; j < n_sh3; j += nt) {
+        const int q = sh0 + j / 3, c = j % 3;
+        const PeerRecvRec r = pm.recv_rec[q];
+        const int n = pm.push_rec[q].info & 0xffff, i = 3 * n + c;
+        const double f = peer_collect(pm, r, q, c, acc[n + c * fstride], pseq);
+        const double u = rec[6 * n + 3 + c];
+        double v = cd_update_dof(f, c == 0 ? 0.0 : fextl[n], massl[n], u, dnl[i], k);  // Dynamic_solver.py:26-32
+        if (tagl[n] & (1 << c)) v = 0.0;
+        if (ap->hist != nullptr) ap->hist[(ap->hist_row0 + s) * ap->width + 3 * (int64_t)r.sidx + c] = v;  // Online_predictor.py:260
+        commit(i, n, c, u, v);
+      }
     }
     tn = tn + k.dt;  // Data_prepare.py:235
     PSTAMP(6)
@@ -922,28 +958,32 @@ int persistent_lds_bytes(int max_local, int max_owned, int max_items, int max_ha
 
 int persistent_max_blocks(int device, int threads, int lds_bytes) {
   int per_cu = 0, cus = 0;
-  if (hipFuncSetAttribute(reinterpret_cast<const void *>(&persistent_steps_kernel<false>),
-                          hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess ||
-      hipFuncSetAttribute(reinterpret_cast<const void *>(&persistent_steps_kernel<true>),
-                          hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess)
+  const void *fns[3] = {reinterpret_cast<const void *>(&persistent_steps_kernel<false, false>),
+                        reinterpret_cast<const void *>(&persistent_steps_kernel<true, false>),
+                        reinterpret_cast<const void *>(&persistent_steps_kernel<false, true>)};
+  for (const void *fn : fns)
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess) return 0;
+  int occ[3] = {0, 0, 0};
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ[0], persistent_steps_kernel<false, false>, threads, lds_bytes) != hipSuccess ||
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ[1], persistent_steps_kernel<true, false>, threads, lds_bytes) != hipSuccess ||
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ[2], persistent_steps_kernel<false, true>, threads, lds_bytes) != hipSuccess)
     return 0;
-  int per_cu_p = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, persistent_steps_kernel<false>, threads, lds_bytes) != hipSuccess ||
-      hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_p, persistent_steps_kernel<true>, threads, lds_bytes) != hipSuccess)
-    return 0;
-  per_cu = per_cu < per_cu_p ? per_cu : per_cu_p;
+  per_cu = occ[0] < occ[1] ? occ[0] : occ[1];
+  per_cu = per_cu < occ[2] ? per_cu : occ[2];
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) return 0;
   return per_cu * cus;
 }
 
 hipError_t launch_persistent_steps(const DeviceMesh &m, int threads, int lds_bytes, hipStream_t st, const StepConsts &k,
-                                   const PersistArgs *args_dev, bool predict) {
+                                   const PersistArgs *args_dev, int mode) {
   DeviceMesh mm = m;
   StepConsts kk = k;
   const PersistArgs *ap = args_dev;
   void *args[] = {&mm, &kk, &ap};
-  const void *fn = predict ? reinterpret_cast<const void *>(&persistent_steps_kernel<true>)
-                           : reinterpret_cast<const void *>(&persistent_steps_kernel<false>);
+  // mode 0: plain steps, 1: predicted phase, 2: synchronised steps with the peer exchange
+  const void *fn = mode == 1   ? reinterpret_cast<const void *>(&persistent_steps_kernel<true, false>)
+                   : mode == 2 ? reinterpret_cast<const void *>(&persistent_steps_kernel<false, true>)
+                               : reinterpret_cast<const void *>(&persistent_steps_kernel<false, false>);
   return hipLaunchCooperativeKernel(fn, dim3(m.n_blocks), dim3(threads), args, lds_bytes, st);
 }
 
