@@ -165,11 +165,19 @@ __device__ __forceinline__ unsigned long long stamp() {
   return t;
 }
 
-template <int ABLATE>
+struct NoHook {
+  __device__ __forceinline__ void operator()() const {}
+};
+// `mid` runs once per call, half-way through the item (after tet A): the resident kernel issues its halo loads there.
+template <int ABLATE, typename Hook = NoHook>
 __device__ __forceinline__ void item_forces(const uint2 w, const double *rec, double *acc, int fstride, int n_owned,
-                                            double lam, double mu, int tid, double &sink, unsigned long long *T = nullptr) {
+                                            double lam, double mu, int tid, double &sink, unsigned long long *T = nullptr,
+                                            Hook mid = Hook()) {
   Item it = unpack(w);
-  if (it.null) return;  // idle lane left by the LDS packing (saa_plan.cpp)
+  if (it.null) {  // idle lane left by the LDS packing (saa_plan.cpp)
+    mid();
+    return;
+  }
   if (ABLATE == 2) {  // every lane reads its own fixed records: no index-dependent LDS traffic
     it.a = tid & 63; it.p = it.a + 1; it.q = it.a + 2; it.r = it.a + 3; it.b = it.a + 4;
   }
@@ -183,6 +191,7 @@ __device__ __forceinline__ void item_forces(const uint2 w, const double *rec, do
                {t, 0, t}, lam, mu, g1, g2, g3);
     sink += fa.x + fa.y + fa.z + fr.x + fr.y + fr.z + fq.x + fq.y + fq.z + g1.x + g1.y + g1.z + g2.x + g2.y + g2.z +
             g3.x + g3.y + g3.z;
+    mid();
     return;
   }
   unsigned long long t0 = 0, t1 = 0;
@@ -208,6 +217,7 @@ __device__ __forceinline__ void item_forces(const uint2 w, const double *rec, do
   }
   if (ABLATE != 1) flush(acc, fstride, it.a, n_owned, fa);
   else sink += fa.x + fa.y + fa.z;
+  mid();
   if (it.pair) {
     const Rec rb = load_rec(rec, it.b);
     if (ABLATE == 8) {
@@ -670,9 +680,7 @@ __global__ void __launch_bounds__(SAA_LB) persistent_steps_kernel(DeviceMesh m, 
   for (int e = tid; e < bd.n_elem; e += nt) connl[e] = m.conn[bd.elem_off + e];
   __syncthreads();
 
-  // boundary sweep starts at the wave after the last interior chunk (see fused_step_kernel)
-  const int shift = (((bd.n_interior + 63) >> 6) % (nt >> 6)) << 6;
-  const int e_b0 = bd.n_interior + (tid >= shift ? tid - shift : tid - shift + nt);
+  const int n_pre = min(bd.n_interior, nt);  // items of the first round: they need no halo record
   const int last = max(bd.n_elem - 1, 0);
   double tn = a.tn0;
   double sink = 0.0;
@@ -691,26 +699,28 @@ __global__ void __launch_bounds__(SAA_LB) persistent_steps_kernel(DeviceMesh m, 
     asm volatile("" : "+v"(ltid));
     const unsigned want = (unsigned)(a.step_base + s);  // stamp of d^(n+s), written by its owner in step s-1
     const PeerEntry *ein = a.entries + (int64_t)(s & 1) * a.entry_stride;
-    // ---- 1. first interior sweep: by its end the neighbours' displacements have landed -----------------
-    if (tid < bd.n_interior) item_forces<0>(connl[tid], rec, acc, fstride, bd.n_owned, m.lambda_, m.mu, tid, sink);
-    PSTAMP(0)
-    // ---- 2. halo displacements: in flight while the remaining interior items run ----------------------
+    // ---- 1. first round: interior items; the halo displacements are requested half-way through it (late enough
+    //         for the neighbours' stores of the previous step to have landed, early enough to arrive by its end) --
     unsigned long long hlo[kPH], hhi[kPH];
-    if (s > 0) {
+    auto fetch = [&]() {
+      if (s > 0) {
 #pragma unroll
-      for (int j = 0; j < kPH; ++j) {
-        const PeerEntry *e = ein + hgl[min(ltid + j * nt, max(n_halo3 - 1, 0))];
-        hlo[j] = __hip_atomic_load(&e->lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        hhi[j] = __hip_atomic_load(&e->hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int j = 0; j < kPH; ++j) {
+          const PeerEntry *e = ein + hgl[min(ltid + j * nt, max(n_halo3 - 1, 0))];
+          hlo[j] = __hip_atomic_load(&e->lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          hhi[j] = __hip_atomic_load(&e->hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
       }
-    }
-    for (int e = tid + nt; e < bd.n_interior; e += nt)
-      item_forces<0>(connl[e], rec, acc, fstride, bd.n_owned, m.lambda_, m.mu, tid, sink);
+    };
+    if (tid < n_pre)
+      item_forces<0>(connl[tid], rec, acc, fstride, bd.n_owned, m.lambda_, m.mu, tid, sink, nullptr, fetch);
+    else
+      fetch();
+    PSTAMP(0)
     PSTAMP(1)
-    // ---- 3. halo displacements -> LDS (an entry still carrying an older stamp is simply read again) ------
+    // ---- 2. halo displacements -> LDS (an entry still carrying an older stamp is simply read again) ------
     if (s > 0) {
-      // (the entry address is recomputed on the rare retry path: keeping it live would cost registers in the
-      // interior loop above)
+      // (the entry address is recomputed on the rare retry path: keeping it live would cost registers)
       auto settle = [&](int i, unsigned long long lo, unsigned long long hi) {
         if ((unsigned)(lo >> 32) != want || (unsigned)(hi >> 32) != want) {
           const PeerEntry *e = ein + hgl[i];
@@ -744,10 +754,11 @@ __global__ void __launch_bounds__(SAA_LB) persistent_steps_kernel(DeviceMesh m, 
     PSTAMP(2)
     lds_barrier();
     PSTAMP(3)
-    // ---- 4. boundary items ----------------------------------------------------------------------------
-    if (e_b0 < bd.n_elem) {
-      uint2 cur = connl[e_b0];
-      for (int e = e_b0; e < bd.n_elem; e += nt) {
+    // ---- 3. the other items in ONE list: the rest of the interior ones, then the boundary ones - no barrier and no
+    //         partly filled round between them -----------------------------------------------------------------
+    if (n_pre + tid < bd.n_elem) {
+      uint2 cur = connl[n_pre + tid];
+      for (int e = n_pre + tid; e < bd.n_elem; e += nt) {
         const uint2 nxt = connl[min(e + nt, last)];
         item_forces<0>(cur, rec, acc, fstride, bd.n_owned, m.lambda_, m.mu, tid, sink);
         cur = nxt;

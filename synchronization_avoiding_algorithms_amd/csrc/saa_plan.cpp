@@ -559,6 +559,12 @@ bool build_once(int32_t n_nodes, int32_t n_elems, const double *xyz, const int32
     }
     fprintf(stderr, "plan: items per block min %d mean %.1f max %d; max interior %d, max boundary %d\n", mn,
             sum / plan.blocks.size(), mx, mxi, mxb);
+    int hist[8][8] = {};
+    for (const auto &b : plan.blocks)
+      hist[std::min(7, (b.n_interior + 1023) / 1024)][std::min(7, (b.n_elem - b.n_interior + 1023) / 1024)]++;
+    for (int i = 0; i < 8; ++i)
+      for (int j = 0; j < 8; ++j)
+        if (hist[i][j]) fprintf(stderr, "plan:   %d blocks with %d interior + %d boundary rounds of 1024 items\n", hist[i][j], i, j);
   }
   if (getenv("SAA_PLAN_DEBUG"))
     fprintf(stderr,
