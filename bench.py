@@ -235,23 +235,33 @@ def main():
         out["sync_avoiding"] = sync_avoiding
     if world == 1:
         # roofline of the dominant (only) kernel: HIP events on the kernel's own stream
-        k = max(200, min(args.steps, 2000))
-        ms = sol.time_steps(k)
+        # one launch of the resident kernel advances `spl` steps (one launch = spl * Ne element-updates); without it
+        # (plan does not fit LDS / not all workgroups co-resident) one launch of the fused kernel is one step
+        res = sol.resident_kernel_info()
+        spl = res["steps_per_launch"] if res["capable"] else 1
+        launches = 3 if spl > 1 else 2000
+        ms = sol.time_steps(launches * spl)
         b_alg = 16 * ne_total + 216 * nn_total
-        achieved = b_alg * k / (ms * 1e-3)
+        achieved = b_alg * launches * spl / (ms * 1e-3)
         out["roofline"] = {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                            "frac": achieved / HBM_PEAK, "traffic": None,
-                           "kernel": "fused_step_kernel<false>", "avg_launch_us": 1e3 * ms / k,
-                           "algorithmic_bytes_per_launch": b_alg,
-                           "algorithmic_bytes_per_element_update": b_alg / ne_total}
+                           "kernel": "persistent_steps_kernel<false,false>" if spl > 1 else "fused_step_kernel<false>",
+                           "steps_per_launch": spl, "avg_launch_us": 1e3 * ms / launches,
+                           "us_per_step": 1e3 * ms / (launches * spl),
+                           "algorithmic_bytes_per_step": b_alg, "algorithmic_bytes_per_launch": b_alg * spl,
+                           "algorithmic_bytes_per_element_update": b_alg / ne_total,
+                           "note": "algorithmic bytes = SURVEY.md section 8(d) figure for a kernel that re-reads the "
+                                   "partition every step; the resident kernel keeps it in LDS and moves less "
+                                   "(see traffic)"}
         # HBM traffic per launch from the committed PMC passes of this same command (rocprofv3 --pmc FETCH_SIZE and
         # --pmc WRITE_SIZE in separate runs; KiB units; FETCH_SIZE doubled: gfx950 counts 64 B per 128-B request,
         # MI355X_MICROARCH.md "HBM").  Only for the meshes that were profiled; otherwise null.
         try:
             with open(os.path.join(REPO, "profiles", "r01_pmc_summary.json")) as fh:
                 pmc = json.load(fh)
-            fetch = pmc[f"q_FETCH_SIZE_{n}:FETCH_SIZE"]["mean_per_dispatch"]
-            write = pmc[f"q_WRITE_SIZE_{n}:WRITE_SIZE"]["mean_per_dispatch"]
+            key = "resident" if spl > 1 else "q"
+            fetch = pmc[f"{key}_FETCH_SIZE_{n}:FETCH_SIZE"]["mean_per_dispatch"]
+            write = pmc[f"{key}_WRITE_SIZE_{n}:WRITE_SIZE"]["mean_per_dispatch"]
             out["roofline"]["traffic"] = (2.0 * fetch + write) * 1024.0
             out["roofline"]["traffic_source"] = "profiles/r01_pmc_summary.json (rocprofv3 --pmc, separate passes)"
         except (OSError, KeyError, ValueError):

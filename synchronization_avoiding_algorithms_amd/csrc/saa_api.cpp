@@ -334,50 +334,62 @@ void setup_persistent(saa_solver *s) {
 
 // nsteps exchange-free steps in ONE cooperative launch; returns SAA_OK with *done = false when the resident kernel
 // does not apply (the caller then launches one fused kernel per step).
+// Exchange-free (or peer-exchange) steps through the resident kernel, in cooperative launches of at most
+// kPersistChunk steps; *n_done = how many of the nsteps were taken that way (0 when the resident kernel does not
+// apply, < nsteps if a launch was refused half-way: the caller takes the rest with one fused kernel per step).
+constexpr int32_t kPersistChunk = 1000;
+
 int try_persistent_steps(saa_solver *s, int32_t nsteps, const double *table_dev, int64_t table_row0, double *hist_dev,
-                         int64_t hist_row0, bool *done, bool peer = false) {
-  *done = false;
+                         int64_t hist_row0, int32_t *n_done, bool peer = false) {
+  *n_done = 0;
   if (!s->ps_capable || nsteps < kPersistMinSteps || !s->mesh.mass_node || !s->mesh.fext_yz) return SAA_OK;
-  saa::PersistArgs a{};
-  a.g0 = s->dbuf[s->i0].p;
-  a.g1 = s->dbuf[s->in_].p;
-  a.entries = s->ps_entries.p;
-  a.entry_stride = 3 * static_cast<int64_t>(s->plan.n_nodes);
-  if (static_cast<uint32_t>(s->ps_steps) > 0x7fff0000u) {  // stamps about to wrap: start over (0 = never written)
-    HIP_TRY(hipMemsetAsync(s->ps_entries.p, 0, s->ps_entries.n * sizeof(saa::PeerEntry), s->stream));
-    s->ps_steps = 0;
-  }
-  a.step_base = s->ps_steps;
-  a.nsteps = nsteps;
-  a.tn0 = s->tn;
-  a.ramp_on = s->ramp;
-  a.max_items = s->ps_max_items;
-  a.table = table_dev;
-  a.hist = hist_dev;
-  a.table_row0 = table_row0;
-  a.hist_row0 = hist_row0;
-  a.width = 3 * static_cast<int64_t>(s->n_shared);
-  a.err = s->ps_err.p;
+  int32_t chunk = kPersistChunk;
+  if (const char *env = std::getenv("SAA_PERSIST_CHUNK")) chunk = std::max(kPersistMinSteps, std::atoi(env));
   double timeout_s = 30.0;
   if (const char *env = std::getenv("SAA_PEER_TIMEOUT_S")) timeout_s = std::max(0.01, std::atof(env));
-  a.timeout_ticks = static_cast<int64_t>(timeout_s * 1e8);
-  // (argument block: stream-ordered copy from pageable memory, staged before the call returns)
-  a.peer = peer ? s->px_map.p : nullptr;
-  a.peer_seq_base = s->peer_seq;
-  if (peer && s->peer_seq > 0xffffffffu - static_cast<uint32_t>(nsteps) - 2u) return SAA_OK;  // wrap: per-step path
-  HIP_TRY(hipMemcpyAsync(s->ps_args.p, &a, sizeof(a), hipMemcpyHostToDevice, s->stream));
-  const hipError_t e = saa::launch_persistent_steps(s->mesh, s->threads, s->ps_lds, s->stream, s->consts, s->ps_args.p,
-                                                    peer ? 2 : (table_dev != nullptr ? 1 : 0));
-  if (e != hipSuccess) {  // e.g. the device cannot hold all workgroups right now: keep the per-step path
-    (void)hipGetLastError();
-    s->ps_capable = false;
-    return SAA_OK;
+  while (*n_done < nsteps) {
+    int32_t n = std::min(chunk, nsteps - *n_done);
+    if (nsteps - *n_done - n > 0 && nsteps - *n_done - n < kPersistMinSteps) n = nsteps - *n_done;  // no tiny tail
+    if (peer && s->peer_seq > 0xffffffffu - static_cast<uint32_t>(n) - 2u) return SAA_OK;  // wrap: per-step path
+    if (static_cast<uint32_t>(s->ps_steps) > 0x7fff0000u) {  // stamps about to wrap: start over (0 = never written)
+      HIP_TRY(hipMemsetAsync(s->ps_entries.p, 0, s->ps_entries.n * sizeof(saa::PeerEntry), s->stream));
+      s->ps_steps = 0;
+    }
+    saa::PersistArgs a{};
+    a.g0 = s->dbuf[s->i0].p;
+    a.g1 = s->dbuf[s->in_].p;
+    a.entries = s->ps_entries.p;
+    a.entry_stride = 3 * static_cast<int64_t>(s->plan.n_nodes);
+    a.step_base = s->ps_steps;
+    a.nsteps = n;
+    a.tn0 = s->tn;
+    a.ramp_on = s->ramp;
+    a.max_items = s->ps_max_items;
+    a.table = table_dev;
+    a.hist = hist_dev;
+    a.table_row0 = table_row0 + *n_done;
+    a.hist_row0 = hist_row0 + *n_done;
+    a.width = 3 * static_cast<int64_t>(s->n_shared);
+    a.err = s->ps_err.p;
+    a.timeout_ticks = static_cast<int64_t>(timeout_s * 1e8);
+    a.peer = peer ? s->px_map.p : nullptr;
+    a.peer_seq_base = s->peer_seq;
+    // argument block: stream-ordered copy from pageable memory (staged before the call returns; lands after the
+    // previous launch, which may still be reading the block, has finished)
+    HIP_TRY(hipMemcpyAsync(s->ps_args.p, &a, sizeof(a), hipMemcpyHostToDevice, s->stream));
+    const hipError_t e = saa::launch_persistent_steps(s->mesh, s->threads, s->ps_lds, s->stream, s->consts,
+                                                      s->ps_args.p, peer ? 2 : (table_dev != nullptr ? 1 : 0));
+    if (e != hipSuccess) {  // e.g. the device cannot hold all workgroups right now: keep the per-step path
+      (void)hipGetLastError();
+      s->ps_capable = false;
+      return SAA_OK;
+    }
+    s->ps_steps = static_cast<int32_t>(static_cast<uint32_t>(s->ps_steps) + static_cast<uint32_t>(n));
+    if (n & 1) std::swap(s->i0, s->in_);
+    for (int32_t k = 0; k < n; ++k) s->tn = s->tn + s->consts.dt;  // the kernel advanced its copy the same way
+    if (peer) s->peer_seq += static_cast<uint32_t>(n);
+    *n_done += n;
   }
-  s->ps_steps = static_cast<int32_t>(static_cast<uint32_t>(s->ps_steps) + static_cast<uint32_t>(nsteps));
-  if (nsteps & 1) std::swap(s->i0, s->in_);
-  for (int32_t k = 0; k < nsteps; ++k) s->tn = s->tn + s->consts.dt;  // the kernel advanced its copy the same way
-  if (peer) s->peer_seq += static_cast<uint32_t>(nsteps);
-  *done = true;
   return SAA_OK;
 }
 
@@ -666,10 +678,9 @@ int saa_step(saa_solver *s, int32_t nsteps) {
   if (!s || nsteps < 0) return fail(SAA_E_ARG, "saa_step: bad argument");
   if (s->pending) return fail(SAA_E_STATE, "saa_step: a synchronised step is in flight");
   HIP_TRY(hipSetDevice(s->device));
-  bool done = false;
-  if (int rc = try_persistent_steps(s, nsteps, nullptr, 0, nullptr, 0, &done)) return rc;
-  if (done) return check_launch();
-  for (int32_t k = 0; k < nsteps; ++k) {
+  int32_t k0 = 0;
+  if (int rc = try_persistent_steps(s, nsteps, nullptr, 0, nullptr, 0, &k0)) return rc;
+  for (int32_t k = k0; k < nsteps; ++k) {
     s->set_ramp();
     saa::launch_fused_step(s->mesh, s->threads, s->lds_bytes, s->stream, s->dbuf[s->i0].p, s->dbuf[s->in_].p,
                            s->dbuf[s->i1].p, nullptr, nullptr, nullptr, s->consts);
@@ -1021,10 +1032,9 @@ int saa_step_peer(saa_solver *s, int32_t nsteps, double *hist_dev, int64_t hist_
   if (s->pending) return fail(SAA_E_STATE, "saa_step_peer: a synchronised step is in flight");
   HIP_TRY(hipSetDevice(s->device));
   const int64_t width = 3 * static_cast<int64_t>(s->n_shared);
-  bool done = false;
-  if (int rc = try_persistent_steps(s, nsteps, nullptr, 0, hist_dev, hist_row0, &done, true)) return rc;
-  if (done) return check_launch();
-  for (int32_t k = 0; k < nsteps; ++k) {
+  int32_t k0 = 0;
+  if (int rc = try_persistent_steps(s, nsteps, nullptr, 0, hist_dev, hist_row0, &k0, true)) return rc;
+  for (int32_t k = k0; k < nsteps; ++k) {
     s->set_ramp();
     if (++s->peer_seq == 0) ++s->peer_seq;  // 0 marks "never written"
     saa::launch_fused_step_peer(s->mesh, s->threads, s->lds_bytes, s->stream, s->dbuf[s->i0].p, s->dbuf[s->in_].p,
@@ -1044,12 +1054,11 @@ int saa_step_predicted(saa_solver *s, int32_t nsteps, const double *table_dev, i
   if (s->pending) return fail(SAA_E_STATE, "saa_step_predicted: a synchronised step is in flight");
   HIP_TRY(hipSetDevice(s->device));
   const int64_t width = 3 * static_cast<int64_t>(s->n_shared);
-  bool done = false;
-  if (int rc = try_persistent_steps(s, nsteps, s->n_shared > 0 ? table_dev : nullptr, table_row0,
-                                    hist_dev, hist_row0, &done))
+  int32_t k0 = 0;
+  if (int rc = try_persistent_steps(s, nsteps, s->n_shared > 0 ? table_dev : nullptr, table_row0, hist_dev, hist_row0,
+                                    &k0))
     return rc;
-  if (done) return check_launch();
-  for (int32_t k = 0; k < nsteps; ++k) {
+  for (int32_t k = k0; k < nsteps; ++k) {
     s->set_ramp();
     // halo overwrite + history record are fused into the step kernel's epilogue (one launch per step)
     saa::launch_fused_step(s->mesh, s->threads, s->lds_bytes, s->stream, s->dbuf[s->i0].p, s->dbuf[s->in_].p,
@@ -1073,6 +1082,16 @@ int saa_halo_scatter(saa_solver *s, const double *row_dev) {
   HIP_TRY(hipSetDevice(s->device));
   saa::launch_halo_overwrite(s->shared, s->stream, row_dev, s->dbuf[s->i0].p, nullptr);
   return check_launch();
+}
+
+int saa_resident_kernel_info(const saa_solver *s, int32_t *capable, int32_t *lds_bytes, int32_t *steps_per_launch) {
+  if (!s) return fail(SAA_E_ARG, "saa_resident_kernel_info: null handle");
+  int32_t chunk = kPersistChunk;
+  if (const char *env = std::getenv("SAA_PERSIST_CHUNK")) chunk = std::max(kPersistMinSteps, std::atoi(env));
+  if (capable) *capable = s->ps_capable && s->mesh.mass_node && s->mesh.fext_yz ? 1 : 0;
+  if (lds_bytes) *lds_bytes = s->ps_lds;
+  if (steps_per_launch) *steps_per_launch = chunk;
+  return SAA_OK;
 }
 
 int saa_synchronize(saa_solver *s) {

@@ -102,6 +102,12 @@ class HipExplicitSolver:
         _lib.check(self._lib.saa_plan_stats_get(self._h, C.byref(st)))
         return st.as_dict()
 
+    def resident_kernel_info(self) -> dict:
+        """Whether multi-step calls run through the resident kernel, its LDS footprint and steps per launch."""
+        cap, lds, spl = C.c_int32(), C.c_int32(), C.c_int32()
+        _lib.check(self._lib.saa_resident_kernel_info(self._h, C.byref(cap), C.byref(lds), C.byref(spl)))
+        return {"capable": bool(cap.value), "lds_bytes": lds.value, "steps_per_launch": spl.value}
+
     def set_stream(self, stream_ptr):
         """``stream_ptr``: integer hipStream_t, e.g. ``torch.cuda.current_stream().cuda_stream``."""
         _lib.check(self._lib.saa_set_stream(self._h, C.c_void_p(int(stream_ptr) if stream_ptr else 0)))

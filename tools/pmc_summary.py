@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Folds rocprofv3 --pmc outputs into profiles/r01_pmc_summary.json.
+
+    python tools/pmc_summary.py <key> <rocprof output dir> [<kernel name substring>] [--steps-only N]
+
+For every counter in the directory's *_counter_collection.csv files: mean value per dispatch of the kernels whose
+name contains the substring (default: "step").  With --grid G only dispatches of that grid size (threads) count,
+which separates the bench mesh from the small meshes other legs of the same command run.
+Entry name: "<key>:<COUNTER>".
+"""
+import csv
+import glob
+import json
+import os
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def main():
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    key, root = args[0], args[1]
+    sub = args[2] if len(args) > 2 else "step"
+    grid = None
+    for a in sys.argv[1:]:
+        if a.startswith("--grid="):
+            grid = int(a.split("=", 1)[1])
+    acc = {}
+    for path in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
+        with open(path, newline="") as fh:
+            for row in csv.DictReader(fh):
+                if sub not in row["Kernel_Name"]:
+                    continue
+                if grid is not None and int(row["Grid_Size"]) != grid:
+                    continue
+                d = acc.setdefault(row["Counter_Name"], {"sum": 0.0, "n": 0, "kernel": row["Kernel_Name"][:80]})
+                d["sum"] += float(row["Counter_Value"])
+                d["n"] += 1
+    out_path = os.path.join(REPO, "profiles", "r01_pmc_summary.json")
+    try:
+        with open(out_path) as fh:
+            summary = json.load(fh)
+    except OSError:
+        summary = {}
+    for name, d in acc.items():
+        summary[f"{key}:{name}"] = {"dispatches": d["n"], "mean_per_dispatch": d["sum"] / max(d["n"], 1),
+                                    "kernel": d["kernel"]}
+        print(f"{key}:{name}", summary[f"{key}:{name}"])
+    with open(out_path, "w") as fh:
+        json.dump(summary, fh, indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    main()
