@@ -263,3 +263,53 @@ def test_per_dof_mass_takes_the_general_path():
         g0, gn, _ = sol.get_state()
         assert rel_l2(g0, o0) < 1e-12 and rel_l2(gn, on) < 1e-12
     sol.close()
+
+
+@pytest.mark.parametrize("n,block_nodes,threads", [(6, 150, 256), (8, 0, 0)])
+def test_resident_kernel_equals_one_launch_per_step(n, block_nodes, threads, monkeypatch):
+    """The resident multi-step kernel (cooperative launches, block image kept in LDS, stamped halo entries) against
+    the fused kernel launched once per step: same arithmetic, so only the order of the LDS atomics differs.  Mixed
+    call lengths exercise the buffer rotation between the two paths and the 1000-step launch chunks."""
+    import torch
+    from synchronization_avoiding_algorithms_amd.mesh import structured_beam
+
+    mesh = structured_beam(n)
+    calls = (1, 9, 2, 1001, 8, 1, 64)
+    monkeypatch.setenv("SAA_NO_PERSISTENT", "1")
+    fused, _, _, _, _ = _serial_solver(mesh, block_nodes=block_nodes, threads=threads)
+    assert not fused.resident_kernel_info()["capable"]
+    monkeypatch.delenv("SAA_NO_PERSISTENT")
+    resident, lay, _, _, _ = _serial_solver(mesh, block_nodes=block_nodes, threads=threads)
+    info = resident.resident_kernel_info()
+    assert info["capable"] and info["steps_per_launch"] == 1000 and info["lds_bytes"] <= 160 * 1024
+    assert resident.plan_stats()["n_blocks"] > 1  # halo entries do travel between workgroups
+    for k in calls:
+        fused.step(k)
+        resident.step(k)
+        a0, an, ta = fused.get_state()
+        b0, bn, tb = resident.get_state()
+        assert ta == tb
+        assert rel_l2(b0, a0) < 1e-12 and rel_l2(bn, an) < 1e-12, k
+    # predicted phase (Online_predictor.py:298-301) through the resident kernel: declared-shared nodes take the
+    # table rows and are recorded; everything else keeps stepping
+    fused.close()
+    resident.close()
+    shared = np.arange(5, 5 + 12, dtype=np.int32)
+    kw = dict(block_nodes=block_nodes, threads=threads, shared_local=shared, shared_slots=np.arange(12, dtype=np.int32),
+              n_global_shared=12)
+    monkeypatch.setenv("SAA_NO_PERSISTENT", "1")
+    fused, _, _, _, _ = _serial_solver(mesh, **kw)
+    monkeypatch.delenv("SAA_NO_PERSISTENT")
+    resident, _, _, _, _ = _serial_solver(mesh, **kw)
+    table = (torch.arange(40 * 36, dtype=torch.float64, device="cuda").reshape(40, 36) - 700.0) * 1e-9
+    h1 = torch.zeros((50, 36), dtype=torch.float64, device="cuda")
+    h2 = torch.zeros_like(h1)
+    for sol, h in ((fused, h1), (resident, h2)):
+        sol.step(20)
+        sol.step_predicted(25, table, 3, h, 10)
+        sol.step(9)
+    torch.cuda.synchronize()
+    assert torch.equal(h1, h2) and torch.equal(h2[10:35], table[3:28])
+    assert rel_l2(resident.get_state()[0], fused.get_state()[0]) < 1e-12
+    fused.close()
+    resident.close()
