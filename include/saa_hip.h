@@ -187,6 +187,9 @@ int saa_halo_scatter(saa_solver *s, const double *row_dev);
  * DESIGN.md section 4) and how much LDS a workgroup of it holds.  capable = 0: the plan does not fit or the device
  * cannot keep all workgroups co-resident; every step is then one launch of the fused kernel. */
 int saa_resident_kernel_info(const saa_solver *s, int32_t *capable, int32_t *lds_bytes, int32_t *steps_per_launch);
+/* enable = 0: keep this handle on one launch per step (for callers that know the device is shared with other
+ * processes: workgroups of a resident kernel that wait for another process' kernel only advance by time-slicing). */
+int saa_set_resident_kernel(saa_solver *s, int32_t enable);
 
 /* Blocks until all work enqueued for this handle has finished. */
 int saa_synchronize(saa_solver *s);

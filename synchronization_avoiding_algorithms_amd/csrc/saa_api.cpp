@@ -124,6 +124,7 @@ struct saa_solver {
   DevBuf<saa::PersistArgs> ps_args;   // argument block of the launch in flight
   int32_t ps_lds = 0, ps_max_items = 0, ps_steps = 0;
   bool ps_capable = false;  // plan fits LDS and all workgroups can be co-resident
+  bool ps_enabled = true;   // saa_set_resident_kernel
   // direct peer exchange (saa_peer_export / saa_peer_attach)
   void *peer_mem = nullptr;          // this rank's exported allocation: flags + inbox (fine-grained)
   int32_t peer_world = 0;
@@ -342,7 +343,8 @@ constexpr int32_t kPersistChunk = 1000;
 int try_persistent_steps(saa_solver *s, int32_t nsteps, const double *table_dev, int64_t table_row0, double *hist_dev,
                          int64_t hist_row0, int32_t *n_done, bool peer = false) {
   *n_done = 0;
-  if (!s->ps_capable || nsteps < kPersistMinSteps || !s->mesh.mass_node || !s->mesh.fext_yz) return SAA_OK;
+  if (!s->ps_capable || !s->ps_enabled || nsteps < kPersistMinSteps || !s->mesh.mass_node || !s->mesh.fext_yz)
+    return SAA_OK;
   int32_t chunk = kPersistChunk;
   if (const char *env = std::getenv("SAA_PERSIST_CHUNK")) chunk = std::max(kPersistMinSteps, std::atoi(env));
   double timeout_s = 30.0;
@@ -1088,9 +1090,15 @@ int saa_resident_kernel_info(const saa_solver *s, int32_t *capable, int32_t *lds
   if (!s) return fail(SAA_E_ARG, "saa_resident_kernel_info: null handle");
   int32_t chunk = kPersistChunk;
   if (const char *env = std::getenv("SAA_PERSIST_CHUNK")) chunk = std::max(kPersistMinSteps, std::atoi(env));
-  if (capable) *capable = s->ps_capable && s->mesh.mass_node && s->mesh.fext_yz ? 1 : 0;
+  if (capable) *capable = s->ps_capable && s->ps_enabled && s->mesh.mass_node && s->mesh.fext_yz ? 1 : 0;
   if (lds_bytes) *lds_bytes = s->ps_lds;
   if (steps_per_launch) *steps_per_launch = chunk;
+  return SAA_OK;
+}
+
+int saa_set_resident_kernel(saa_solver *s, int32_t enable) {
+  if (!s) return fail(SAA_E_ARG, "saa_set_resident_kernel: null handle");
+  s->ps_enabled = enable != 0;
   return SAA_OK;
 }
 

@@ -108,6 +108,9 @@ class HipExplicitSolver:
         _lib.check(self._lib.saa_resident_kernel_info(self._h, C.byref(cap), C.byref(lds), C.byref(spl)))
         return {"capable": bool(cap.value), "lds_bytes": lds.value, "steps_per_launch": spl.value}
 
+    def set_resident_kernel(self, enable: bool):
+        _lib.check(self._lib.saa_set_resident_kernel(self._h, 1 if enable else 0))
+
     def set_stream(self, stream_ptr):
         """``stream_ptr``: integer hipStream_t, e.g. ``torch.cuda.current_stream().cuda_stream``."""
         _lib.check(self._lib.saa_set_stream(self._h, C.c_void_p(int(stream_ptr) if stream_ptr else 0)))
