@@ -106,6 +106,54 @@ def cpu_baseline_and_parity(sample_n=10, steps=12000, parity_steps=3000):
             {"rel_l2": rel, "mesh": f"synthetic beam n={sample_n}", "steps": parity_steps, "tolerance": 1e-10})
 
 
+def preflight_main(world, rank, local_rank):
+    """Child process of one rank (bench.py --preflight): a tiny partitioned problem stepped through the peer exchange
+    on the real devices.  Exit code 0 = the direct xGMI path works here; anything else (including a crash of this
+    process) makes the parent fall back to the RCCL all-reduce."""
+    import torch
+    import torch.distributed as dist
+
+    import datetime
+
+    torch.cuda.set_device(local_rank)
+    dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=90))  # a crashed peer must not park the others
+    from synchronization_avoiding_algorithms_amd.distributed import PartitionedSolver
+    from synchronization_avoiding_algorithms_amd.mesh import slab_partition, structured_beam
+
+    mesh = structured_beam(4)
+    part = PartitionedSolver(mesh.points, mesh.tets, mesh.triangles, slab_partition(mesh, world), rank, world, E=E, nu=NU,
+                             rho=RHO, fz=FZ, alpha=ALPHA, gamma=GAMMA, device=local_rank, exchange="peer")
+    ok = part.exchange == "peer"
+    if ok:
+        part.step_synced(5)      # one launch per step
+        part.step_synced(120)    # resident kernel
+        d0 = part.get_state()[0]
+        ok = bool(np.isfinite(d0).all() and np.abs(d0).max() > 0)
+    flags = [None] * world
+    dist.all_gather_object(flags, ok)
+    part.close()
+    dist.destroy_process_group()
+    return 0 if all(flags) else 3
+
+
+def run_preflight(args, world):
+    """Runs preflight_main in a child process BEFORE this process touches the GPU; True iff it exited cleanly."""
+    import subprocess
+
+    env = dict(os.environ)
+    env["MASTER_PORT"] = str(int(env.get("MASTER_PORT", "29500")) + 17)
+    env.pop("TORCHELASTIC_USE_AGENT_STORE", None)  # the children's rank 0 hosts their own rendezvous store
+    env["SAA_PEER_TIMEOUT_S"] = env.get("SAA_PEER_TIMEOUT_S", "20")
+    try:
+        cmd = [sys.executable, os.path.abspath(__file__), "--preflight", "--gpus", str(world)]
+        if args.same_device:
+            cmd.append("--same-device")
+        r = subprocess.run(cmd, env=env, timeout=420, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        return r.returncode == 0
+    except Exception:  # noqa: BLE001 - timeout, spawn failure
+        return False
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -124,10 +172,8 @@ def main():
                          "ncclAllReduce from C++, torch = torch.distributed.all_reduce; auto tries them in that order")
     ap.add_argument("--same-device", action="store_true",
                     help="rehearsal on a one-GPU box: every rank uses cuda:0 (needs --backend gloo)")
+    ap.add_argument("--preflight", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
-
-    import torch
-    import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -136,6 +182,18 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if args.same_device:
         local_rank = 0
+    if args.preflight:
+        raise SystemExit(preflight_main(world, rank, local_rank))
+    # N > 1: the direct peer exchange maps other processes' device memory - first use on this machine happens in a
+    # child process, so that a fault there costs the child, not the benchmark (which then takes the RCCL all-reduce)
+    exchange = "torch" if args.torch_exchange else args.exchange
+    peer_ok = True
+    if world > 1 and exchange == "auto" and (not args.same_device or os.environ.get("SAA_BENCH_FORCE_PREFLIGHT")):
+        peer_ok = run_preflight(args, world)
+
+    import torch
+    import torch.distributed as dist
+
     torch.cuda.set_device(local_rank)
     if world > 1:
         if args.backend == "nccl":
@@ -146,13 +204,19 @@ def main():
     from synchronization_avoiding_algorithms_amd.distributed import PartitionedSolver
     from synchronization_avoiding_algorithms_amd.mesh import slab_partition, structured_beam
 
+    if world > 1 and exchange == "auto":  # every rank takes the same transport
+        flags = [None] * world
+        dist.all_gather_object(flags, bool(peer_ok))
+        if not all(flags):
+            exchange = "rccl"
+    preflight = None if world == 1 or args.exchange != "auto" or args.torch_exchange else bool(peer_ok)
     n = args.refine or N_FOR_GPUS.get(world, int(round((world * 1028850 / 150.0) ** (1 / 3))))
     mesh = structured_beam(n)
     ne_total, nn_total = len(mesh.tets), len(mesh.points)
     epart = slab_partition(mesh, world) if world > 1 else np.zeros(ne_total, dtype=np.int64)
     part = PartitionedSolver(mesh.points, mesh.tets, mesh.triangles, epart, rank, world, E=E, nu=NU, rho=RHO,
                              fz=FZ, alpha=ALPHA, gamma=GAMMA, device=local_rank, block_nodes=args.block_nodes,
-                             threads=args.threads, exchange="torch" if args.torch_exchange else args.exchange)
+                             threads=args.threads, exchange=exchange)
     sol, gshared, dt = part.solver, part.global_shared, part.dt
 
     def run(k):
@@ -233,6 +297,8 @@ def main():
         }
     if rank == 0 and sync_avoiding is not None:
         out["sync_avoiding"] = sync_avoiding
+    if rank == 0 and world > 1:
+        out["config"]["peer_preflight_rank0"] = preflight  # child-process trial of the peer exchange (None: not run)
     if world == 1:
         # roofline of the dominant (only) kernel: HIP events on the kernel's own stream
         # one launch of the resident kernel advances `spl` steps (one launch = spl * Ne element-updates); without it
