@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Diagnostic: where a step of the resident kernel spends its cycles (build with -DSAA_PERSIST_STAMPS).
 
-    hipcc ... -DSAA_PERSIST_STAMPS -o tools/exp/libsaa_stamps.so ; SAA_LIB_PATH=tools/exp/libsaa_stamps.so python tools/persist_stamps.py
+    cd synchronization_avoiding_algorithms_amd/csrc && hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC -shared \
+        -munsafe-fp-atomics -DSAA_PERSIST_STAMPS saa_kernels.hip saa_api.cpp saa_plan.cpp -o ../../tools/exp/libsaa_stamps.so -ldl
+    SAA_LIB_PATH=tools/exp/libsaa_stamps.so python tools/persist_stamps.py
 """
 import os
 import sys
@@ -30,11 +32,11 @@ _lib.check(lib.saa_step_predicted(sol._h, C.c_int32(steps), C.c_void_p(dbg.data_
                                   C.c_void_p(dbg.data_ptr()), C.c_int64(0)))
 sol.synchronize()
 t = dbg.cpu().numpy().view(np.uint64).reshape(waves, 8).astype(np.float64) / steps
-names = ["interior sweep 1", "issue halo loads + interior rest", "settle halo -> LDS", "barrier (halo)",
-         "boundary items", "barrier (slowest wave)", "update", "barrier (end of step)"]
+names = ["round 1 (interior items, halo fetch issued)", "-", "settle halo -> LDS", "barrier (halo)",
+         "other interior + boundary items", "barrier (slowest wave)", "update", "barrier (end of step)"]
 tot = t.sum(axis=1)
 print(f"n={n} plan {st}")
-print(f"cycles per step per wave (100 MHz? no: shader clock), median total {np.median(tot):.0f}")
+print(f"shader-clock cycles per step per wave, median total {np.median(tot):.0f}")
 for j, nm in enumerate(names):
     print(f"  {nm:34s} median {np.median(t[:, j]):8.0f}  p90 {np.percentile(t[:, j], 90):8.0f}  max {t[:, j].max():8.0f}")
 ms = sol.time_steps(1000)
