@@ -111,7 +111,10 @@ class PartitionedSolver:
         info = (ok, handle, self.device_ordinal, slots, order)
         box = [None] * self.world
         dist.all_gather_object(box, info, group=self.group)
-        if len({b[2] for b in box}) < self.world and hasattr(self.solver, "set_resident_kernel"):
+        import os
+
+        if (len({b[2] for b in box}) < self.world and hasattr(self.solver, "set_resident_kernel")
+                and os.environ.get("SAA_FORCE_RESIDENT") != "1"):  # (the override is for tests of that very path)
             # ranks sharing one GPU (rehearsals, the one-GPU test box): a resident kernel waiting for another
             # process' kernel only advances by time-slicing - keep one launch per step
             self.solver.set_resident_kernel(False)

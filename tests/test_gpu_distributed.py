@@ -219,6 +219,43 @@ def test_three_ranks_on_one_gpu_equal_serial(tmp_path, exchange):
     _check_three_ranks(tmp_path, use_gpu=True, exchange=exchange)
 
 
+def _resident_peer_worker(rank, world, port, out_dir):
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0",
+                      SAA_FORCE_RESIDENT="1", SAA_PEER_TIMEOUT_S="20")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from synchronization_avoiding_algorithms_amd.distributed import PartitionedSolver
+
+    g = np.load(os.path.join(GOLDEN, "beam_coarse_mesh.npz"))
+    t = np.load(os.path.join(GOLDEN, "tworank_trajectory.npz"))
+    part = PartitionedSolver(g["points"], g["tetra"], g["triangle"], t["epart"], rank, world, device=0, exchange="peer")
+    assert part.exchange == "peer" and part.solver.resident_kernel_info()["capable"]
+    hist = torch.zeros((100, part.input_size), dtype=torch.float64, device="cuda")
+    part.step_synced(1, hist, 0)     # one launch per step
+    part.step_synced(9, hist, 1)     # resident kernel: pushes / collects between two processes inside the step loop
+    d10 = part.get_state()[0][:, 0]
+    part.step_synced(90, hist, 10)
+    d100 = part.get_state()[0][:, 0]
+    torch.cuda.synchronize()
+    assert np.array_equal(hist[99].cpu().numpy(), d100[part.layout.loc_dof_shared])
+    np.savez(os.path.join(out_dir, f"res{rank}.npz"), d10=d10, d100=d100)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_resident_kernel_with_peer_exchange_between_processes(tmp_path):
+    """The PEER variant of the resident kernel with a real second process (both on the test GPU; the two small
+    cooperative kernels only advance each other by time-slicing, so the step count is kept low)."""
+    port = 41500 + os.getpid() % 2000
+    mp.spawn(_resident_peer_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    t = load_golden("tworank_trajectory.npz")
+    for r in range(2):
+        got = np.load(tmp_path / f"res{r}.npz")
+        assert rel_l2(got["d10"], t[f"r{r}_step_10"]) < 1e-14
+        assert rel_l2(got["d100"], t[f"r{r}_step_100"]) < 1e-13
+
+
 def _dead_peer_worker(rank, world, port, out_dir):
     sys.path.insert(0, REPO)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0",
