@@ -193,10 +193,10 @@ void fill_stats(const saa::Plan &plan, int lds, int threads, saa_plan_stats *out
 }
 
 bool build_fitting_plan(int32_t n_nodes, int32_t n_elems, const double *xyz, const int32_t *tets,
-                        int32_t block_nodes, saa::Plan &plan, std::string &err) {
+                        int32_t block_nodes, saa::Plan &plan, std::string &err, const int32_t *extra_work = nullptr) {
   int32_t bn = block_nodes;  // <= 0: automatic (saa_plan.cpp)
   while (true) {
-    if (!saa::build_plan(n_nodes, n_elems, xyz, tets, bn, plan, err)) return false;
+    if (!saa::build_plan(n_nodes, n_elems, xyz, tets, bn, plan, err, extra_work)) return false;
     if (lds_bytes_of(plan) <= kLdsBudget) return true;
     if (bn <= 0) bn = std::max(plan.max_owned, 16);
     if (bn <= 8) {
@@ -449,7 +449,18 @@ int saa_create(const saa_problem *pb, saa_solver **out) {
   saa_solver *s = new (std::nothrow) saa_solver();
   if (!s) return fail(SAA_E_HIP, "saa_create: out of host memory");
   std::string err;
-  if (!build_fitting_plan(pb->n_nodes, pb->n_elems, pb->xyz, pb->tets, pb->block_nodes, s->plan, err)) {
+  // a shared node costs its workgroup a push to and a collect from the neighbour ranks on top of its elements
+  // (tools/peer_loopback.py: ~1.9 us for ~95 shared nodes against ~11 us for ~5300 element copies): the blocks are
+  // balanced with that in mind, so that interface blocks are not the ones every other block waits for
+  std::vector<int32_t> extra;
+  if (pb->n_shared > 0) {
+    int32_t per_node = 16;  // 10 is the optimum with local latency (loop-back); xGMI's is longer
+    if (const char *env = std::getenv("SAA_SHARED_NODE_WORK")) per_node = std::max(0, std::atoi(env));
+    extra.assign(pb->n_nodes, 0);
+    for (int32_t i = 0; i < pb->n_shared; ++i) extra[pb->shared_nodes[i]] = per_node;
+  }
+  if (!build_fitting_plan(pb->n_nodes, pb->n_elems, pb->xyz, pb->tets, pb->block_nodes, s->plan, err,
+                          extra.empty() ? nullptr : extra.data())) {
     delete s;
     return fail(err.find("LDS") != std::string::npos ? SAA_E_CAPACITY : SAA_E_ARG, err);
   }

@@ -19,6 +19,7 @@ struct Rcb {
   const double *xyz;
   std::vector<int32_t> &order;          // node ids being permuted in place
   std::vector<int32_t> &block_start;    // filled leaf by leaf, in order
+  const int64_t *weight = nullptr;      // per node (caller's id): work it brings to its block; null = 1
   void split(int64_t lo, int64_t hi, int32_t nblk) {
     if (nblk <= 1) {
       std::sort(order.begin() + lo, order.begin() + hi);
@@ -41,12 +42,22 @@ struct Rcb {
     for (int a = 1; a < 3; ++a)
       if (mx[a] - mn[a] > mx[ax] - mn[ax]) ax = a;
     const double *c = xyz;
-    std::nth_element(order.begin() + lo, order.begin() + lo + k, order.begin() + hi,
-                     [c, ax](int32_t a, int32_t b) {
-                       const double va = c[3 * static_cast<int64_t>(a) + ax];
-                       const double vb = c[3 * static_cast<int64_t>(b) + ax];
-                       return va < vb || (va == vb && a < b);
-                     });
+    auto before = [c, ax](int32_t a, int32_t b) {
+      const double va = c[3 * static_cast<int64_t>(a) + ax];
+      const double vb = c[3 * static_cast<int64_t>(b) + ax];
+      return va < vb || (va == vb && a < b);
+    };
+    if (weight) {  // cut where the left part holds its share of the WORK, not of the nodes
+      std::sort(order.begin() + lo, order.begin() + hi, before);
+      int64_t total = 0;
+      for (int64_t i = lo; i < hi; ++i) total += weight[order[i]];
+      const int64_t want = (total * left_blk + nblk / 2) / nblk;
+      int64_t acc = 0, kk = 0;
+      while (kk < n - 1 && acc + weight[order[lo + kk]] / 2 < want) acc += weight[order[lo + kk++]];
+      k = std::max<int64_t>(left_blk, std::min<int64_t>(n - (nblk - left_blk), std::max<int64_t>(1, kk)));
+    } else {
+      std::nth_element(order.begin() + lo, order.begin() + lo + k, order.begin() + hi, before);
+    }
     split(lo, lo + k, left_blk);
     split(lo + k, hi, nblk - left_blk);
   }
@@ -344,7 +355,7 @@ int32_t reorder_for_lds(const uint16_t *items, int32_t n_items, int32_t n_owned,
 
 // ------------------------------------------------------------------------------------------------
 bool build_once(int32_t n_nodes, int32_t n_elems, const double *xyz, const int32_t *tets,
-                int32_t block_nodes, Plan &plan, std::string &err, bool &too_big) {
+                int32_t block_nodes, Plan &plan, std::string &err, bool &too_big, const int32_t *extra_work) {
   too_big = false;
   plan = Plan();
   plan.n_nodes = n_nodes;
@@ -356,7 +367,57 @@ bool build_once(int32_t n_nodes, int32_t n_elems, const double *xyz, const int32
   std::vector<int32_t> block_start;
   block_start.reserve(nb + 1);
   Rcb rcb{xyz, plan.new_to_old, block_start};
-  rcb.split(0, n_nodes, nb);
+  // A block's work is its element copies, not its nodes: blocks in the bulk (more elements per node, every face
+  // shared with a neighbour) must get fewer nodes than blocks at the surface, or the slowest block - which paces
+  // all the others, directly in the resident kernel - carries ~10 % more items than the mean.  Weighted bisection:
+  // a node weighs the elements around it, then the weights of every block are rescaled by its measured
+  // copies / mean and the bisection is repeated (a few rounds; it only moves the cuts).
+  std::vector<int64_t> weight;
+  const char *wenv = getenv("SAA_PLAN_WEIGHTED");
+  if (nb > 1 && !(wenv && wenv[0] == '0')) {
+    weight.assign(n_nodes, 1024);
+    for (int64_t i = 0; i < 4 * static_cast<int64_t>(n_elems); ++i) weight[tets[i]] += 1024;
+    if (extra_work)
+      for (int32_t i = 0; i < n_nodes; ++i) weight[i] += 4096ll * extra_work[i];  // a copy weighs ~4 node-valences
+    rcb.weight = weight.data();
+    std::vector<int32_t> owner(n_nodes), copies;
+    for (int round = 0; round < 4; ++round) {
+      std::iota(plan.new_to_old.begin(), plan.new_to_old.end(), 0);
+      block_start.clear();
+      rcb.split(0, n_nodes, nb);
+      const int32_t nblk = static_cast<int32_t>(block_start.size());
+      for (int32_t b = 0; b < nblk; ++b) {
+        const int32_t end = b + 1 < nblk ? block_start[b + 1] : n_nodes;
+        for (int32_t i = block_start[b]; i < end; ++i) owner[plan.new_to_old[i]] = b;
+      }
+      copies.assign(nblk, 0);
+      for (int32_t e = 0; e < n_elems; ++e) {
+        int32_t bs[4];
+        int cnt = 0;
+        for (int a = 0; a < 4; ++a) {
+          const int32_t b = owner[tets[4 * static_cast<int64_t>(e) + a]];
+          bool seen = false;
+          for (int j = 0; j < cnt; ++j) seen |= (bs[j] == b);
+          if (!seen) bs[cnt++] = b;
+        }
+        for (int j = 0; j < cnt; ++j) ++copies[bs[j]];
+      }
+      if (extra_work)
+        for (int32_t i = 0; i < n_nodes; ++i) copies[owner[i]] += extra_work[i];
+      double mean = 0;
+      int32_t mx = 0;
+      for (int32_t c : copies) {
+        mean += c;
+        mx = std::max(mx, c);
+      }
+      mean /= nblk;
+      if (round == 3 || mx <= 1.015 * mean) break;
+      for (int32_t i = 0; i < n_nodes; ++i)
+        weight[i] = std::max<int64_t>(1, static_cast<int64_t>(weight[i] * (copies[owner[i]] / mean)));
+    }
+  } else {
+    rcb.split(0, n_nodes, nb);
+  }
   block_start.push_back(n_nodes);
   const int32_t n_blocks = static_cast<int32_t>(block_start.size()) - 1;
 
@@ -578,7 +639,7 @@ bool build_once(int32_t n_nodes, int32_t n_elems, const double *xyz, const int32
 }  // namespace
 
 bool build_plan(int32_t n_nodes, int32_t n_elems, const double *xyz, const int32_t *tets,
-                int32_t block_nodes, Plan &plan, std::string &err) {
+                int32_t block_nodes, Plan &plan, std::string &err, const int32_t *extra_work) {
   if (n_nodes <= 0 || n_elems < 0 || !xyz || (n_elems > 0 && !tets)) {
     err = "build_plan: empty mesh or null pointer";
     return false;
@@ -598,7 +659,7 @@ bool build_plan(int32_t n_nodes, int32_t n_elems, const double *xyz, const int32
   bn = std::min(bn, kMaxLocalNodes);
   while (true) {
     bool too_big = false;
-    if (build_once(n_nodes, n_elems, xyz, tets, bn, plan, err, too_big)) return true;
+    if (build_once(n_nodes, n_elems, xyz, tets, bn, plan, err, too_big, extra_work)) return true;
     if (!too_big) return false;
     if (bn <= 8) {
       err = "build_plan: a node block exceeds the LDS budget even with 8 owned nodes "

@@ -64,7 +64,9 @@ constexpr int32_t kDefaultBlockNodes = 384;
 constexpr int32_t kLargeMeshBlockNodes = 720;  // partitions too large for one block per CU
 
 // Builds the plan; on failure returns false and fills err.  block_nodes <= 0 selects the default.
+// extra_work (nullable, per node in the caller's numbering): work a node brings to its block besides its elements,
+// in units of element copies (e.g. the peer exchange of a shared node); the blocks are balanced on the sum.
 bool build_plan(int32_t n_nodes, int32_t n_elems, const double *xyz, const int32_t *tets,
-                int32_t block_nodes, Plan &plan, std::string &err);
+                int32_t block_nodes, Plan &plan, std::string &err, const int32_t *extra_work = nullptr);
 
 }  // namespace saa

@@ -32,3 +32,12 @@ def rel_l2(a, b):
     b = np.asarray(b, dtype=np.float64).ravel()
     nb = np.linalg.norm(b)
     return np.linalg.norm(a - b) / nb if nb > 0 else np.linalg.norm(a)
+
+
+def free_port():
+    """A TCP port nobody listens on right now (for the rendezvous of spawned ranks)."""
+    import socket
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]

@@ -8,7 +8,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from conftest import GOLDEN, REPO, load_golden, rel_l2
+from conftest import GOLDEN, REPO, free_port, load_golden, rel_l2
 
 
 def _worker(rank, world, port, steps, out_dir):
@@ -41,7 +41,7 @@ def _worker(rank, world, port, steps, out_dir):
 
 def test_two_rank_sync_matches_reference(tmp_path):
     steps = (1, 10, 100, 1000)
-    port = 29500 + os.getpid() % 2000
+    port = free_port()
     mp.spawn(_worker, args=(2, port, steps, str(tmp_path)), nprocs=2, join=True)
     t = load_golden("tworank_trajectory.npz")
     bound = {1: 1e-15, 10: 1e-14, 100: 1e-13, 1000: 5e-12}
@@ -106,7 +106,7 @@ def _hybrid_worker(rank, world, port, out_dir):
 
 def test_two_rank_hybrid_loop_matches_reference(tmp_path):
     """Online_predictor.py:251-318 re-enacted by distributed.run_hybrid + the batched predictor."""
-    port = 31500 + os.getpid() % 2000
+    port = free_port()
     mp.spawn(_hybrid_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     h = load_golden("hybrid_tworank.npz")
     i_cri = int(h["n_past"]) * int(h["filter_size"]) - 1
@@ -152,7 +152,7 @@ def _check_three_ranks(tmp_path, use_gpu, exchange="auto"):
     from synchronization_avoiding_algorithms_amd import fem_setup as fs
     from synchronization_avoiding_algorithms_amd.mesh import clamp_nodes, structured_beam
 
-    port = 37500 + os.getpid() % 2000 + (7 if use_gpu else 0) + (13 if exchange == "peer" else 0)
+    port = free_port()
     mp.spawn(_three_rank_worker, args=(3, port, str(tmp_path), use_gpu, exchange), nprocs=3, join=True)
     mesh = structured_beam(3, length=4.0)
     layouts, gshared = fs.build_layouts(mesh.tets, _t_partition(mesh), 3, len(mesh.points), clamp_nodes(mesh))

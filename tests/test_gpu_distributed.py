@@ -10,7 +10,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from conftest import GOLDEN, REPO, load_golden, rel_l2
+from conftest import GOLDEN, REPO, free_port, load_golden, rel_l2
 
 pytestmark = pytest.mark.gpu
 
@@ -54,7 +54,7 @@ def test_two_ranks_on_one_gpu_match_reference(tmp_path, exchange):
     """``peer``: shared-node forces stored straight into the other rank's inbox through HIP IPC (the path the
     multi-GPU bench takes over xGMI); ``torch``: begin / all_reduce / finish."""
     steps = (1, 10, 100, 1000, 5000)
-    port = 29500 + os.getpid() % 2000 + (11 if exchange == "peer" else 0)
+    port = free_port()
     mp.spawn(_worker, args=(2, port, steps, str(tmp_path), exchange), nprocs=2, join=True)
     t = load_golden("tworank_trajectory.npz")
     bound = {1: 1e-15, 10: 1e-14, 100: 1e-13, 1000: 5e-12, 5000: 5e-11}
@@ -96,7 +96,7 @@ def _workflow_worker(rank, world, port, out_dir):
 def test_reference_workflow_on_gpu(tmp_path):
     """Data_prepare -> Shared_extraction -> Online_predictor (README.md:33-38) with the HIP solver and the
     GPU-batched LSTM, against the same chain run by the reference itself (hybrid_tworank.npz)."""
-    port = 33500 + os.getpid() % 2000
+    port = free_port()
     mp.spawn(_workflow_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     h = load_golden("hybrid_tworank.npz")
     i_cri = int(h["n_past"]) * int(h["filter_size"]) - 1
@@ -188,7 +188,7 @@ def _nccl_single_worker(rank, world, port, out_dir):
 def test_native_exchange_next_to_torch_nccl(tmp_path):
     """torch.distributed(nccl) and saa_comm_init use the same librccl.so in one process without disturbing
     each other (one rank; the multi-rank collective itself needs the driver's multi-GPU node)."""
-    port = 35500 + os.getpid() % 2000
+    port = free_port()
     mp.spawn(_nccl_single_worker, args=(1, port, str(tmp_path)), nprocs=1, join=True)
     got = np.load(tmp_path / "nccl1.npy")
     ref = load_golden("serial_trajectory.npz")
@@ -247,7 +247,7 @@ def _resident_peer_worker(rank, world, port, out_dir):
 def test_resident_kernel_with_peer_exchange_between_processes(tmp_path):
     """The PEER variant of the resident kernel with a real second process (both on the test GPU; the two small
     cooperative kernels only advance each other by time-slicing, so the step count is kept low)."""
-    port = 41500 + os.getpid() % 2000
+    port = free_port()
     mp.spawn(_resident_peer_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     t = load_golden("tworank_trajectory.npz")
     for r in range(2):
@@ -286,6 +286,6 @@ def _dead_peer_worker(rank, world, port, out_dir):
 
 
 def test_peer_exchange_times_out_instead_of_hanging(tmp_path):
-    port = 39500 + os.getpid() % 2000
+    port = free_port()
     mp.spawn(_dead_peer_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert "timed out waiting for a neighbour" in (tmp_path / "dead0.txt").read_text()

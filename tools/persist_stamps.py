@@ -15,10 +15,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import build_rank_solver  # noqa: E402
 from synchronization_avoiding_algorithms_amd.mesh import structured_beam  # noqa: E402
 
+# usage: persist_stamps.py [n [parts rank]]   (parts > 1: the x-slab partition `rank` of `parts`, exchange-free steps)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 19
+parts = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+prank = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 steps = 1000
 mesh = structured_beam(n)
-sol, lay, _, _ = build_rank_solver(mesh, 1, 0, 0)
+sol, lay, _, _ = build_rank_solver(mesh, parts, prank, 0)
 st = sol.plan_stats()
 waves = st["n_blocks"] * st["threads"] // 64
 dbg = torch.zeros(8 * waves, dtype=torch.float64, device="cuda")  # reinterpreted as uint64 by the kernel
