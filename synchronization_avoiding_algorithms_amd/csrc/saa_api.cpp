@@ -125,6 +125,7 @@ struct saa_solver {
   int32_t ps_lds = 0, ps_max_items = 0, ps_steps = 0;
   bool ps_capable = false;  // plan fits LDS and all workgroups can be co-resident
   bool ps_enabled = true;   // saa_set_resident_kernel
+  double *ps_dbg = nullptr; // diagnostic builds (-DSAA_PERSIST_STAMPS): where the per-wave cycle counts go
   // direct peer exchange (saa_peer_export / saa_peer_attach)
   void *peer_mem = nullptr;          // this rank's exported allocation: flags + inbox (fine-grained)
   int32_t peer_world = 0;
@@ -368,7 +369,7 @@ int try_persistent_steps(saa_solver *s, int32_t nsteps, const double *table_dev,
     a.ramp_on = s->ramp;
     a.max_items = s->ps_max_items;
     a.table = table_dev;
-    a.hist = hist_dev;
+    a.hist = hist_dev ? hist_dev : (table_dev == nullptr && !peer ? s->ps_dbg : nullptr);
     a.table_row0 = table_row0 + *n_done;
     a.hist_row0 = hist_row0 + *n_done;
     a.width = 3 * static_cast<int64_t>(s->n_shared);
@@ -1199,6 +1200,14 @@ int saa_debug_time_peer(saa_solver *s, int32_t nsteps, double *elapsed_ms) {
   (void)hipEventDestroy(a);
   (void)hipEventDestroy(b);
   return rc ? rc : check_peer_error(s);
+}
+
+// Diagnostic (tools/persist_stamps.py): buffer of 8 * waves uint64 that a -DSAA_PERSIST_STAMPS build of the resident
+// kernel fills with per-wave cycle counts during plain saa_step calls; the product build never touches it.
+int saa_debug_set_stamp_buffer(saa_solver *s, double *buf_dev) {
+  if (!s) return fail(SAA_E_ARG, "saa_debug_set_stamp_buffer: null handle");
+  s->ps_dbg = buf_dev;
+  return SAA_OK;
 }
 
 // Diagnostic: copies the stamps of the last variant-8 launch to the host (n = 12 * blocks * waves values).

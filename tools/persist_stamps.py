@@ -25,15 +25,16 @@ sol, lay, _, _ = build_rank_solver(mesh, parts, prank, 0)
 st = sol.plan_stats()
 waves = st["n_blocks"] * st["threads"] // 64
 dbg = torch.zeros(8 * waves, dtype=torch.float64, device="cuda")  # reinterpreted as uint64 by the kernel
-# the stamped build writes through PersistArgs::hist: hand it over with a zero-width "table" (n_shared = 0)
-sol.step(200)
-sol.synchronize()
 import ctypes as C
 from synchronization_avoiding_algorithms_amd import _lib
 lib = _lib.load()
-_lib.check(lib.saa_step_predicted(sol._h, C.c_int32(steps), C.c_void_p(dbg.data_ptr()), C.c_int64(0),
-                                  C.c_void_p(dbg.data_ptr()), C.c_int64(0)))
+lib.saa_debug_set_stamp_buffer.restype = C.c_int
+sol.step(200)
 sol.synchronize()
+_lib.check(lib.saa_debug_set_stamp_buffer(sol._h, C.c_void_p(dbg.data_ptr())))
+sol.step(steps)   # one launch of `steps` steps: the counts are per launch
+sol.synchronize()
+_lib.check(lib.saa_debug_set_stamp_buffer(sol._h, None))
 t = dbg.cpu().numpy().view(np.uint64).reshape(waves, 8).astype(np.float64) / steps
 names = ["round 1 (interior items, halo fetch issued)", "-", "settle halo -> LDS", "barrier (halo)",
          "other interior + boundary items", "barrier (slowest wave)", "update", "barrier (end of step)"]
