@@ -597,36 +597,29 @@ __global__ void peer_selftest_kernel(PeerMap pm, const double *__restrict__ own,
 //   rec   [max_local][6]  x y z ux uy uz   (x static; u of owned nodes updated in place, u of halo nodes re-read)
 //   acc   3 force planes,  dnl [3*max_owned] d^(n-1) of the owned dofs,
 //   massl / fextl [max_owned] nodal mass and (0,v,v) load,  tagl [max_owned],  connl [max_items] work items,
-// so that per step only 24 B per owned node leave the CU (new displacements) and 24 B per halo node enter it.
+//   hgl [3*max_halo] entry index of every halo dof,
+// so that per step only 48 B per owned node leave the CU (new displacements as stamped entries) and 48 B per halo
+// node enter it.
 // Step s of a block needs d^(n+s) of its halo nodes, written by their owners at the end of step s-1.  No flags, no
 // grid barrier: every published value is a 16-byte entry of two words, each = 32 bits of the double + the 32-bit
-// step count (the protocol of the peer exchange above), so a reader can load speculatively - after its first
-// interior sweep, consumed after the rest of the interior items - and recognise a value that has not arrived yet.
+// step count (the protocol of the peer exchange above), so a reader can load speculatively - half-way through its
+// first round of interior items, consumed at the end of that round - and recognise a value that has not arrived yet.
 // Two entry buffers alternate by step parity: an owner cannot overwrite what a reader still needs, because it cannot
 // get two steps ahead of a block it reads from.
 // All workgroups must be co-resident (cooperative launch); every wait is bounded (PersistArgs::timeout_ticks).
 // ---------------------------------------------------------------------------------------------
-// Cross-workgroup traffic of the resident kernel uses agent-scope relaxed atomics only (global_load/store ... sc1:
-// served by / written through to the level all XCDs share) plus execution barriers and vmcnt waits - no L2
-// write-back or invalidate inside the step loop (an acquire in a polling loop would invalidate the XCD's L2 on
-// every iteration).
-__device__ __forceinline__ void store_agent(double *p, double v) {
-  __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v),
-                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ double load_agent(const double *p) {
-  return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(p),
-                                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-}
+// Cross-workgroup traffic of the resident kernel uses agent-scope relaxed accesses only (global_load/store ... sc1:
+// served by / written through to the level all XCDs share) - no L2 write-back or invalidate inside the step loop
+// (an acquire in a polling loop would invalidate the XCD's L2 on every iteration).
 
 __host__ __device__ inline int persist_off_dn(int max_local, int fstride) { return 6 * max_local + 3 * fstride; }
 
-// PREDICT: the predicted phase (table / history rows); a separate instantiation keeps its pointers out of the plain
-// kernel's scalar registers.  The argument block is read from device memory where it is needed for the same reason.
 #ifndef SAA_PERSIST_PRE
 #define SAA_PERSIST_PRE 2
 #endif
-constexpr int kPH = SAA_PERSIST_PRE;  // stamped halo entries per thread in flight across the interior items
+constexpr int kPH = SAA_PERSIST_PRE;  // stamped halo entries per thread in flight during the first round
+// PREDICT: the predicted phase (table / history rows); a separate instantiation keeps its pointers out of the plain
+// kernel's scalar registers.  The argument block is read from device memory where it is needed for the same reason.
 // PEER: synchronised steps with the direct peer exchange (shared nodes pushed to / collected from the neighbour
 // ranks inside the step loop, like fused_step_kernel<.., PEER>).
 template <bool PREDICT, bool PEER>
