@@ -6,6 +6,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 import shutil
 import subprocess
 
@@ -127,6 +128,14 @@ def load():
         raise RuntimeError(
             f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
             "(the HIP extension is mandatory; there is no CPU fallback)")
+    # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64.so.  If libsaa_hip.so came first it would
+    # pull in the system copy under the same soname and a later `import torch` would find "No HIP GPUs".  Loading
+    # torch first makes both use torch's copy (the package needs torch anyway for streams and device buffers).
+    if "torch" not in sys.modules:
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)
