@@ -80,7 +80,7 @@ typedef struct saa_plan_stats {
 } saa_plan_stats;
 
 const char *saa_last_error(void);
-/* Library / ABI version; bumps when a signature in this header changes. */
+/* Library / ABI version; bumps when this header changes (2: peer exchange and resident-kernel entry points). */
 int32_t saa_abi_version(void);
 
 /* Build the device-resident solver for one partition.  Replaces, for this path,

@@ -408,7 +408,7 @@ extern "C" {
 
 const char *saa_last_error(void) { return g_last_error.c_str(); }
 
-int32_t saa_abi_version(void) { return 1; }
+int32_t saa_abi_version(void) { return 2; }  // 2: peer exchange and resident-kernel entry points added
 
 int saa_plan_host_stats(int32_t n_nodes, int32_t n_elems, const double *xyz, const int32_t *tets,
                         int32_t block_nodes, saa_plan_stats *out) {

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for name in _declared_functions():
         assert hasattr(lib, name), name
-    assert _lib.load().saa_abi_version() == 1
+    assert _lib.load().saa_abi_version() == 2
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
