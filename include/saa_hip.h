@@ -109,6 +109,10 @@ int saa_set_loads(saa_solver *s, const double *f_ext_host, const double *lumped_
 /* f = K_local . d without K: backs `LocalK.dot(T.d0)` (Dynamic_solver.py:12).  Host in, host out,
  * 3*n_nodes doubles each. */
 int saa_internal_force(saa_solver *s, const double *d_host, double *f_host);
+/* Same with caller-owned DEVICE buffers (3*n_nodes doubles each, caller numbering), enqueued on the handle's stream:
+ * the operator of iterative solvers that keep their vectors on the GPU - the matrix-free replacement of
+ * `np.linalg.solve(K, F)` in Steady_Elasticity_solver (Tools/Steady_solvers.py:13-22, Data_prepare.py:163). */
+int saa_internal_force_device(saa_solver *s, const double *d_dev, double *f_dev);
 
 /* One damped central-difference update on the host-provided arrays, evaluated on the GPU in the
  * reference's association order (Dynamic_solver.py:13-20).  Backs the drop-in

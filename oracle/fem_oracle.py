@@ -186,6 +186,25 @@ def lumped_mass_and_load(cells, points, rho, fz):
     return lumped.reshape(-1, 1), F.reshape(-1, 1)
 
 
+def steady_solve(cells, points, dirichlet_dofs, lmd, mu, rho, fz):
+    """``Steady_Elasticity_solver`` (Steady_solvers.py:13-22) with ``Global_Assembly`` (Mat_construction.py:154-196):
+    rows and columns of Dirichlet dofs are never assembled, their diagonal is set to 1 and their load to 0, then
+    ``d = K^-1 F`` with the un-ramped load.  Sparse direct solve here instead of the dense one."""
+    from scipy.sparse import identity
+    from scipy.sparse.linalg import spsolve
+
+    n = len(points)
+    K = assemble_local_stiffness(np.arange(n), cells, points, lmd, mu)
+    _, F = lumped_mass_and_load(cells, points, rho, fz)
+    free = np.ones(3 * n)
+    free[np.asarray(dirichlet_dofs, dtype=np.int64)] = 0.0
+    from scipy.sparse import diags
+
+    Dm = diags(free)
+    A = (Dm @ K @ Dm + diags(1.0 - free)).tocsc()
+    return spsolve(A, F.ravel() * free).reshape(-1, 1)
+
+
 def meshsize(cells, points):
     """``Meshsize`` (commons.py:79-90): 2*min_edge/sqrt(24) over the given elements."""
     P = points[np.asarray(cells, dtype=np.int64)]

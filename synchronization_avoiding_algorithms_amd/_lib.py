@@ -69,6 +69,7 @@ SIGNATURES = {
     "saa_get_state_device": (C.c_int, [_H, C.c_void_p, C.c_void_p]),
     "saa_set_loads": (C.c_int, [_H, _dp, _dp]),
     "saa_internal_force": (C.c_int, [_H, _dp, _dp]),
+    "saa_internal_force_device": (C.c_int, [_H, C.c_void_p, C.c_void_p]),
     "saa_cd_update": (C.c_int, [_H, _dp, _dp, _dp, C.c_double, _dp]),
     "saa_step": (C.c_int, [_H, C.c_int32]),
     "saa_set_interface_buffer": (C.c_int, [_H, C.c_void_p]),

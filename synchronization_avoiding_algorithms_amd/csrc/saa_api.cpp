@@ -673,6 +673,16 @@ int saa_internal_force(saa_solver *s, const double *d_host, double *f_host) {
   return download_permuted(s, s->scratch[1].p, f_host);
 }
 
+int saa_internal_force_device(saa_solver *s, const double *d_dev, double *f_dev) {
+  if (!s || !d_dev || !f_dev) return fail(SAA_E_ARG, "saa_internal_force_device: null argument");
+  HIP_TRY(hipSetDevice(s->device));
+  if (int rc = ensure_scratch(s, 2)) return rc;
+  saa::launch_permute(s->plan.n_nodes, s->new_to_old.p, s->stream, d_dev, s->scratch[0].p);
+  saa::launch_force_only(s->mesh, s->threads, s->lds_bytes, s->stream, s->scratch[0].p, s->scratch[1].p);
+  saa::launch_unpermute(s->plan.n_nodes, s->new_to_old.p, s->stream, s->scratch[1].p, f_dev);
+  return check_launch();
+}
+
 int saa_cd_update(saa_solver *s, const double *f_int_host, const double *d0_host, const double *dn_host,
                   double tn, double *d1_host) {
   if (!s || !f_int_host || !d0_host || !dn_host || !d1_host) return fail(SAA_E_ARG, "saa_cd_update: null argument");

@@ -129,6 +129,7 @@ void launch_halo_overwrite(const SharedMap &sh, hipStream_t st, const double *ro
 void launch_halo_gather(const SharedMap &sh, hipStream_t st, const double *d, double *row);
 void launch_cd_update(const DeviceMesh &m, hipStream_t st, const double *f_int, const double *d0,
                       const double *dn, double *d1, const StepConsts &k);
+void launch_permute(int n_nodes, const int32_t *new_to_old, hipStream_t st, const double *in, double *out);
 void launch_unpermute(int n_nodes, const int32_t *new_to_old, hipStream_t st, const double *in, double *out);
 
 }  // namespace saa

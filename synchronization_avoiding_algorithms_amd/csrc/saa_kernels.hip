@@ -900,6 +900,16 @@ __global__ void unpermute_kernel(int n_nodes, const int32_t *__restrict__ new_to
   }
 }
 
+// caller order -> internal order
+__global__ void permute_kernel(int n_nodes, const int32_t *__restrict__ new_to_old, const double *__restrict__ in,
+                               double *__restrict__ out) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < 3 * (int64_t)n_nodes) {
+    const int n = (int)(i / 3), c = (int)(i - 3 * (int64_t)n);
+    out[i] = in[3 * (int64_t)new_to_old[n] + c];
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // launchers (called from saa_api.cpp through saa_device.h)
 // ---------------------------------------------------------------------------------------------
@@ -1024,6 +1034,12 @@ void launch_cd_update(const DeviceMesh &m, hipStream_t st, const double *f_int, 
   const int64_t n = 3 * (int64_t)m.n_nodes;
   hipLaunchKernelGGL(cd_update_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, m, f_int, d0, dn,
                      d1, k);
+}
+
+void launch_permute(int n_nodes, const int32_t *new_to_old, hipStream_t st, const double *in, double *out) {
+  const int64_t n = 3 * (int64_t)n_nodes;
+  hipLaunchKernelGGL(permute_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n_nodes, new_to_old, in,
+                     out);
 }
 
 void launch_unpermute(int n_nodes, const int32_t *new_to_old, hipStream_t st, const double *in, double *out) {

@@ -27,6 +27,7 @@ from .mesh import rcb_partition, read_vtk, slab_partition, structured_beam
 
 # constants of Data_prepare.py:35-50 / Online_predictor.py:38-63
 DEFAULTS = dict(E=1e6, nu=0.3, rho=1.0, fz=0.5, alpha=0.5, gamma=0.9)
+STEADY_PATH = "Results/Static/steady_distributed.vtk"   # Data_prepare.py:25,168
 PATHS = dict(local_nodes="Results/Rankwised_Data/Rank={r}_local_nodes.csv",
              shared="Results/Shared_Data/Rank={r}_shared.csv",
              global_shared="Results/Shared_Data/Global_shared.csv",
@@ -97,6 +98,33 @@ def data_prepare(mesh, n_steps=100000, save_every=1, out_dir=".", rank=0, world=
     return path, store
 
 
+def steady_state(mesh, out_dir=".", device=0, tol=1e-12, verbose=False, E=None, nu=None, rho=None, fz=None):
+    """``Data_prepare.py:157-168`` (rank 0 in the reference): the steady solution ``d = K^-1 F`` of the whole mesh
+    under the un-ramped load, written as point data of ``Results/Static/steady_distributed.vtk``.  Matrix-free
+    preconditioned CG on one GPU (:mod:`steady`) instead of the dense solve."""
+    from . import fem_setup as fs
+    from .mesh import clamp_nodes
+    from .solver import HipExplicitSolver
+    from .steady import steady_solve, stiffness_diagonal, write_vtk_point_data
+
+    E = DEFAULTS["E"] if E is None else E
+    nu = DEFAULTS["nu"] if nu is None else nu
+    rho = DEFAULTS["rho"] if rho is None else rho
+    fz = DEFAULTS["fz"] if fz is None else fz
+    lmd, mu = fs.lame(E, nu)
+    lumped, fpre = fs.lumped_mass_and_load(mesh.points, mesh.tets, rho, fz)
+    dirichlet = fs.node_to_dof(clamp_nodes(mesh))
+    sol = HipExplicitSolver(mesh.points, mesh.tets, lumped, fpre, dirichlet, lmd, mu,
+                            fs.cfl_dt(mesh.points, mesh.tets, E, nu, rho, DEFAULTS["gamma"]), DEFAULTS["alpha"],
+                            device=device)
+    d, iters, rel = steady_solve(sol, fpre, dirichlet, diag=stiffness_diagonal(mesh.points, mesh.tets, lmd, mu), tol=tol)
+    sol.close()
+    if verbose:
+        print(f"steady solve: {iters} CG iterations, relative residual {rel:.2e}, max|d| = {np.abs(d).max():.6e}")
+    path = write_vtk_point_data(os.path.join(out_dir, STEADY_PATH), mesh.points, mesh.tets, d)
+    return path, d
+
+
 def shared_extraction(out_dir=".", rank=0):
     """``Shared_extraction.py:22-40``: rows ``shared_dof`` of the rank's trajectory."""
     local = rio.load_int_list(os.path.join(out_dir, PATHS["local_nodes"].format(r=rank)))
@@ -147,7 +175,8 @@ def _load_mesh(args):
 
 def main(argv=None):
     ap = argparse.ArgumentParser(prog="synchronization_avoiding_algorithms_amd.drivers")
-    ap.add_argument("command", choices=["data_prepare", "shared_extraction", "model_training", "online_predictor"])
+    ap.add_argument("command", choices=["data_prepare", "steady_state", "shared_extraction", "model_training",
+                                        "online_predictor"])
     ap.add_argument("--epochs", type=int, default=None, help="model_training: override the epoch count")
     ap.add_argument("--mesh", default="Mesh_info/beam_coarse.vtk")
     ap.add_argument("--synthetic", type=int, default=0, help="use the 25n x n x n synthetic beam instead")
@@ -164,6 +193,10 @@ def main(argv=None):
     if args.command == "data_prepare":
         path, _ = data_prepare(_load_mesh(args), args.steps, args.save_every, args.out, rank, world,
                                args.partition, device=local, verbose=True)
+    elif args.command == "steady_state":
+        if rank != 0:
+            return
+        path, _ = steady_state(_load_mesh(args), args.out, device=local, verbose=True)
     elif args.command == "shared_extraction":
         path, _ = shared_extraction(args.out, rank)
     elif args.command == "model_training":

@@ -68,6 +68,7 @@ class HipExplicitSolver:
         self.n_shared = int(sn.size)
         self.n_global_shared = int(n_global_shared)
         self.dt = float(dt)
+        self.device = int(device)
         pb = _lib.Problem(
             n_nodes=self.n_nodes, n_elems=self.n_elems, xyz=_dptr(pts), tets=_iptr(tets),
             lumped_mass=_dptr(mass), f_ext=_dptr(fext), dirichlet_dofs=_iptr(dd), n_dirichlet=dd.size,
@@ -144,6 +145,13 @@ class HipExplicitSolver:
         a, f = _f64(d, self.n_dof), np.empty(self.n_dof)
         _lib.check(self._lib.saa_internal_force(self._h, _dptr(a), _dptr(f)))
         return f.reshape(-1, 1)
+
+    def internal_force_device(self, d, out):
+        """``out = K_local . d`` for float64 CUDA tensors of ``3*n_nodes`` values (caller numbering)."""
+        if d.numel() != self.n_dof or out.numel() != self.n_dof:
+            raise ValueError(f"expected {self.n_dof} values")
+        _lib.check(self._lib.saa_internal_force_device(self._h, _dev(d), _dev(out)))
+        return out
 
     def cd_update(self, f_int, d0, dn, tn):
         a, b, c = _f64(f_int, self.n_dof), _f64(d0, self.n_dof), _f64(dn, self.n_dof)
