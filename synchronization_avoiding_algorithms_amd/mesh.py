@@ -171,6 +171,20 @@ def slab_partition(mesh: Mesh, n_parts: int, axis: int = 0) -> np.ndarray:
     order = np.argsort(cent, kind="stable")
     epart = np.empty(len(cent), dtype=np.int64)
     bounds = elmdist(len(cent), n_parts)
+    # Layered meshes (few distinct node coordinates along the axis, e.g. the synthetic beams): move every cut to the
+    # nearest node plane, so that an interface is one plane of nodes instead of a ragged band two layers thick
+    # (twice the shared nodes for a 0.4 % better element balance).
+    planes = np.unique(mesh.points[:, axis])
+    if 2 < len(planes) <= 8192 and len(planes) * 4 < len(mesh.points):
+        sorted_cent = cent[order]
+        for r in range(1, n_parts):
+            k = int(bounds[r])
+            if 0 < k < len(cent):
+                cut = 0.5 * (sorted_cent[k - 1] + sorted_cent[k])
+                plane = planes[np.argmin(np.abs(planes - cut))]
+                bounds[r] = int(np.searchsorted(sorted_cent, plane, side="left"))
+        for r in range(1, n_parts):  # keep the slabs non-empty and ordered
+            bounds[r] = min(max(bounds[r], bounds[r - 1] + 1), len(cent) - (n_parts - r))
     for r in range(n_parts):
         epart[order[bounds[r]: bounds[r + 1]]] = r
     return epart
