@@ -1,5 +1,11 @@
+#!/usr/bin/env python3
+"""Diagnostic: every rank's partition of the N = 2, 4, 8 bench configurations on ONE GPU - plan, whether the
+resident kernel holds it, and its exchange-free step time (the slowest rank paces a synchronised run).
+
+    python tools/rank_survey.py
+"""
 import os, sys, time
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from bench import N_FOR_GPUS, E, NU, RHO, FZ, ALPHA, GAMMA
 import synchronization_avoiding_algorithms_amd as saa
