@@ -294,6 +294,8 @@ __device__ __forceinline__ double peer_wait(const PeerMap &pm, const PeerEntry *
     lo = __hip_atomic_load(&src->lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     hi = __hip_atomic_load(&src->hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if ((unsigned)(lo >> 32) == seq && (unsigned)(hi >> 32) == seq) break;
+    // slow path only: a wait that already failed somewhere in this launch is not repeated for every later value
+    if (__hip_atomic_load(pm.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) break;
     if (wall_clock64() - t0 > pm.timeout_ticks) {  // a neighbour died or never attached: report, do not hang
       __hip_atomic_store(pm.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       break;
@@ -719,9 +721,11 @@ __global__ void __launch_bounds__(SAA_LB) persistent_steps_kernel(DeviceMesh m, 
           const PeerEntry *e = ein + hgl[i];
           const long long t0 = wall_clock64();
           do {
+            int32_t *errp = *(int32_t *volatile const *)&ap->err;
+            if (__hip_atomic_load(errp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) break;  // failed before
             if (wall_clock64() - t0 > *(volatile const int64_t *)&ap->timeout_ticks) {
               // workgroups not co-resident, or a fault elsewhere: report, do not hang
-              __hip_atomic_store(*(int32_t *volatile const *)&ap->err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+              __hip_atomic_store(errp, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
               break;
             }
             __builtin_amdgcn_s_sleep(1);
