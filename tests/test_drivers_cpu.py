@@ -44,3 +44,22 @@ def test_results_io_roundtrip(tmp_path):
     assert rio.load_int_list(str(tmp_path / "l.csv")).tolist() == [4, 2, 9]
     rio.save_int_list(str(tmp_path / "one.csv"), [7])
     assert rio.load_int_list(str(tmp_path / "one.csv")).tolist() == [7]
+
+
+def test_slab_partition_cuts_layered_meshes_on_node_planes():
+    """The multi-GPU bench partitions (8 x-slabs, 7 interface planes x 1521 nodes at n=38):
+    on a layered mesh every interface is ONE plane of nodes shared by exactly two parts."""
+    from synchronization_avoiding_algorithms_amd import fem_setup as fs
+    from synchronization_avoiding_algorithms_amd.mesh import clamp_nodes, slab_partition, structured_beam
+
+    n, parts = 4, 3
+    mesh = structured_beam(n)
+    epart = slab_partition(mesh, parts)
+    counts = np.bincount(epart, minlength=parts)
+    assert counts.min() > 0 and counts.max() - counts.min() <= 6 * n * n  # at most one layer of cubes apart
+    layouts, gshared = fs.build_layouts(mesh.tets, epart, parts, len(mesh.points), clamp_nodes(mesh))
+    assert len(gshared) == (parts - 1) * (n + 1) ** 2
+    assert [len(lay.shared_nodes) for lay in layouts] == [(n + 1) ** 2, 2 * (n + 1) ** 2, (n + 1) ** 2]
+    for g in range(parts - 1):  # the nodes of one interface share one x coordinate
+        left, right = set(layouts[g].nodes.tolist()), set(layouts[g + 1].nodes.tolist())
+        assert len(np.unique(mesh.points[sorted(left & right), 0])) == 1
