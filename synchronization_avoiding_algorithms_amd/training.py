@@ -53,30 +53,34 @@ def model_train(device, model, batches, criterion, optimizer, n_future):
     """One epoch of recursive-decoding training (``DNN_tools.py:103-165``, 'recursive' method).
     Returns (sum of batch losses, sum of R2 accuracies, sum of relative accuracies, model)."""
     model.train()
-    loss_sum = r2_sum = rel_sum = 0.0
+    # the three running sums stay on the device (float64, like the reference's Python floats) and come back once per
+    # epoch: a .item() per batch would stall the launch-bound GPU three times per optimiser step
+    sums = torch.zeros(3, dtype=torch.float64, device=device)
     for X, Y in batches:
         optimizer.zero_grad()
         out = _decode(model, X, n_future)
         loss = criterion(out, Y)
         with torch.no_grad():
-            r2_sum += (1.0 - loss / criterion(Y, torch.mean(Y) + torch.zeros_like(Y))).item()
-            rel_sum += (1.0 - loss / criterion(Y, torch.zeros_like(Y))).item()
-        loss_sum += loss.item()
+            sums[1] += (1.0 - loss / criterion(Y, torch.mean(Y) + torch.zeros_like(Y))).double()
+            sums[2] += (1.0 - loss / criterion(Y, torch.zeros_like(Y))).double()
+            sums[0] += loss.detach().double()
         loss.backward()
         optimizer.step()
+    loss_sum, r2_sum, rel_sum = sums.tolist()
     return loss_sum, r2_sum, rel_sum, model
 
 
 def model_test(device, model, batches, criterion, n_future):
     """Validation pass (``DNN_tools.py:170-207``)."""
     model.eval()
-    loss_sum = r2_sum = rel_sum = 0.0
+    sums = torch.zeros(3, dtype=torch.float64, device=device)
     with torch.no_grad():
         for X, Y in batches:
             loss = criterion(_decode(model, X, n_future), Y)
-            loss_sum += loss.item()
-            r2_sum += (1.0 - loss / criterion(Y, torch.mean(Y) + torch.zeros_like(Y))).item()
-            rel_sum += (1.0 - loss / criterion(Y, torch.zeros_like(Y))).item()
+            sums[0] += loss.double()
+            sums[1] += (1.0 - loss / criterion(Y, torch.mean(Y) + torch.zeros_like(Y))).double()
+            sums[2] += (1.0 - loss / criterion(Y, torch.zeros_like(Y))).double()
+    loss_sum, r2_sum, rel_sum = sums.tolist()
     return loss_sum, r2_sum, rel_sum
 
 
