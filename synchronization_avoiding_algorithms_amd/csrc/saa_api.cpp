@@ -349,7 +349,7 @@ int try_persistent_steps(saa_solver *s, int32_t nsteps, const double *table_dev,
   int32_t chunk = kPersistChunk;
   if (const char *env = std::getenv("SAA_PERSIST_CHUNK")) chunk = std::max(kPersistMinSteps, std::atoi(env));
   double timeout_s = 30.0;
-  if (const char *env = std::getenv("SAA_PEER_TIMEOUT_S")) timeout_s = std::max(0.01, std::atof(env));
+  if (const char *env = std::getenv("SAA_PEER_TIMEOUT_S")) timeout_s = std::max(1e-7, std::atof(env));
   while (*n_done < nsteps) {
     int32_t n = std::min(chunk, nsteps - *n_done);
     if (nsteps - *n_done - n > 0 && nsteps - *n_done - n < kPersistMinSteps) n = nsteps - *n_done;  // no tiny tail
@@ -1009,7 +1009,7 @@ static int peer_attach_impl(saa_solver *s, int32_t rank, int32_t world, const ui
   pm.parity_stride = per_me * world;
   pm.err = s->px_err.p;
   double timeout_s = 30.0;
-  if (const char *env = std::getenv("SAA_PEER_TIMEOUT_S")) timeout_s = std::max(0.01, std::atof(env));
+  if (const char *env = std::getenv("SAA_PEER_TIMEOUT_S")) timeout_s = std::max(1e-7, std::atof(env));
   pm.timeout_ticks = static_cast<int64_t>(timeout_s * 1e8);  // wall_clock64(): 100 MHz
   pm.rank = rank;
   pm.world = world;
