@@ -676,7 +676,8 @@ __global__ void __launch_bounds__(SAA_LB) persistent_steps_kernel(DeviceMesh m, 
   __syncthreads();
 
   const int n_pre = min(bd.n_interior, nt);  // items of the first round: they need no halo record
-  const int last = max(bd.n_elem - 1, 0);
+  const int n_ir = bd.n_interior - n_pre, n_ir_pad = (n_ir + 63) & ~63;  // interior items left for the second phase
+  const int n_post = n_ir_pad + (bd.n_elem - bd.n_interior);
   double tn = a.tn0;
   double sink = 0.0;
 #ifdef SAA_PERSIST_STAMPS
@@ -753,13 +754,11 @@ __global__ void __launch_bounds__(SAA_LB) persistent_steps_kernel(DeviceMesh m, 
     PSTAMP(3)
     // ---- 3. the other items in ONE list: the rest of the interior ones, then the boundary ones - no barrier and no
     //         partly filled round between them -----------------------------------------------------------------
-    if (n_pre + tid < bd.n_elem) {
-      uint2 cur = connl[n_pre + tid];
-      for (int e = n_pre + tid; e < bd.n_elem; e += nt) {
-        const uint2 nxt = connl[min(e + nt, last)];
-        item_forces<0>(cur, rec, acc, fstride, bd.n_owned, m.lambda_, m.mu, tid, sink);
-        cur = nxt;
-      }
+    //         The boundary part starts on a wave boundary (the interior part is padded to a multiple of 64 slots):
+    //         the plan packed each list for the LDS banks from ITS first item, in groups of 16 / 32 lanes.
+    for (int p = tid; p < n_post; p += nt) {
+      const int e = p < n_ir_pad ? (p < n_ir ? n_pre + p : -1) : bd.n_interior + (p - n_ir_pad);
+      if (e >= 0) item_forces<0>(connl[e], rec, acc, fstride, bd.n_owned, m.lambda_, m.mu, tid, sink);
     }
     PSTAMP(4)
     lds_barrier();
