@@ -181,6 +181,14 @@ int saa_step_peer(saa_solver *s, int32_t nsteps, double *hist_dev, int64_t hist_
 int saa_step_predicted(saa_solver *s, int32_t nsteps, const double *table_dev, int64_t table_row0,
                        double *hist_dev, int64_t hist_row0);
 
+/* Trajectory recorder: the ground-truth loop's `d1_save[:, counter] = d1` (Data_prepare.py:236-240; likewise
+ * Online_predictor.py:316-318) without leaving the GPU.  traj_dev is a caller-owned DEVICE matrix, row-major
+ * (3*n_nodes, n_cols) in the caller's dof order - the layout of the reference's `Displacement` dataset.  From now on
+ * every step taken through this handle (any stepping entry point, resident kernel included) has a step index,
+ * starting at next_step_index; the displacement d^(n+1) of step index i is written to column i / save_every
+ * whenever i % save_every == 0 and that column exists.  traj_dev = NULL switches the recorder off. */
+int saa_set_recorder(saa_solver *s, double *traj_dev, int64_t n_cols, int32_t save_every, int64_t next_step_index);
+
 /* d_sol_shared[i,:] = d0[loc_dof_shared] (Online_predictor.py:260,301) / the reverse overwrite
  * (:298) on the CURRENT d0, for callers that drive single steps themselves. */
 int saa_halo_gather(saa_solver *s, double *row_dev);

@@ -79,6 +79,7 @@ SIGNATURES = {
     "saa_comm_init": (C.c_int, [_H, C.c_char_p, C.POINTER(C.c_uint8), C.c_int32, C.c_int32]),
     "saa_step_synced": (C.c_int, [_H, C.c_int32, C.c_void_p, C.c_int64]),
     "saa_resident_kernel_info": (C.c_int, [_H, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "saa_set_recorder": (C.c_int, [_H, C.c_void_p, C.c_int64, C.c_int32, C.c_int64]),
     "saa_set_resident_kernel": (C.c_int, [_H, C.c_int32]),
     "saa_peer_export": (C.c_int, [_H, C.c_int32, C.POINTER(C.c_uint8), C.POINTER(C.c_int32)]),
     "saa_peer_attach": (C.c_int, [_H, C.c_int32, C.c_int32, C.POINTER(C.c_uint8), C.POINTER(C.c_int32),

@@ -125,6 +125,10 @@ struct saa_solver {
   int32_t ps_lds = 0, ps_max_items = 0, ps_steps = 0;
   bool ps_capable = false;  // plan fits LDS and all workgroups can be co-resident
   bool ps_enabled = true;   // saa_set_resident_kernel
+  // trajectory recorder (saa_set_recorder)
+  double *rec_traj = nullptr;
+  int64_t rec_cols = 0, rec_index = 0;
+  int32_t rec_every = 1;
   double *ps_dbg = nullptr; // diagnostic builds (-DSAA_PERSIST_STAMPS): where the per-wave cycle counts go
   // direct peer exchange (saa_peer_export / saa_peer_attach)
   void *peer_mem = nullptr;          // this rank's exported allocation: flags + inbox (fine-grained)
@@ -148,6 +152,13 @@ struct saa_solver {
     in_ = i0;
     i0 = i1;
     i1 = old_n;
+    record_if_due();
+  }
+  // per-step paths: the state that has just become d^n is a column of the caller's trajectory if its step index is due
+  void record_if_due() {
+    if (rec_traj && rec_index % rec_every == 0 && rec_index / rec_every < rec_cols)
+      saa::launch_record_column(plan.n_nodes, new_to_old.p, stream, dbuf[i0].p, rec_traj, rec_cols, rec_index / rec_every);
+    ++rec_index;
   }
   void set_ramp() { consts.ramp = ramp ? (tn <= 1 ? tn : 1.0) : 1.0; }  // commons.py:7-11
   void release_all() {
@@ -377,6 +388,11 @@ int try_persistent_steps(saa_solver *s, int32_t nsteps, const double *table_dev,
     a.timeout_ticks = static_cast<int64_t>(timeout_s * 1e8);
     a.peer = peer ? s->px_map.p : nullptr;
     a.peer_seq_base = s->peer_seq;
+    a.traj = s->rec_traj;
+    a.new_to_old = s->new_to_old.p;
+    a.traj_cols = s->rec_cols;
+    a.step_index0 = s->rec_index;
+    a.save_every = s->rec_every;
     // argument block: stream-ordered copy from pageable memory (staged before the call returns; lands after the
     // previous launch, which may still be reading the block, has finished)
     HIP_TRY(hipMemcpyAsync(s->ps_args.p, &a, sizeof(a), hipMemcpyHostToDevice, s->stream));
@@ -391,6 +407,7 @@ int try_persistent_steps(saa_solver *s, int32_t nsteps, const double *table_dev,
     if (n & 1) std::swap(s->i0, s->in_);
     for (int32_t k = 0; k < n; ++k) s->tn = s->tn + s->consts.dt;  // the kernel advanced its copy the same way
     if (peer) s->peer_seq += static_cast<uint32_t>(n);
+    s->rec_index += n;
     *n_done += n;
   }
   return SAA_OK;
@@ -1115,6 +1132,18 @@ int saa_resident_kernel_info(const saa_solver *s, int32_t *capable, int32_t *lds
   if (capable) *capable = s->ps_capable && s->ps_enabled && s->mesh.mass_node && s->mesh.fext_yz ? 1 : 0;
   if (lds_bytes) *lds_bytes = s->ps_lds;
   if (steps_per_launch) *steps_per_launch = chunk;
+  return SAA_OK;
+}
+
+int saa_set_recorder(saa_solver *s, double *traj_dev, int64_t n_cols, int32_t save_every, int64_t next_step_index) {
+  if (!s) return fail(SAA_E_ARG, "saa_set_recorder: null handle");
+  if (traj_dev && (n_cols <= 0 || save_every <= 0 || next_step_index < 0))
+    return fail(SAA_E_ARG, "saa_set_recorder: bad argument");
+  if (s->pending) return fail(SAA_E_STATE, "saa_set_recorder: a synchronised step is in flight");
+  s->rec_traj = traj_dev;
+  s->rec_cols = traj_dev ? n_cols : 0;
+  s->rec_every = traj_dev ? save_every : 1;
+  s->rec_index = traj_dev ? next_step_index : 0;
   return SAA_OK;
 }
 

@@ -107,7 +107,17 @@ struct PersistArgs {
   int64_t timeout_ticks;
   const PeerMap *peer;      // device copy of the peer map (synchronised steps with the peer exchange), or nullptr
   uint32_t peer_seq_base;   // sequence number of the last exchange before this launch
+  // trajectory recorder (saa_set_recorder): d^(n+1) of step index i goes to column i / save_every of a row-major
+  // (3*n_nodes, n_cols) matrix in the CALLER's dof order whenever i % save_every == 0 (Data_prepare.py:238-240)
+  double *traj;             // or nullptr
+  const int32_t *new_to_old;
+  int64_t traj_cols, step_index0;  // step index of the first step of this launch
+  int32_t save_every;
 };
+
+// Recorder of the per-step paths: one small kernel after a step that is due.
+void launch_record_column(int n_nodes, const int32_t *new_to_old, hipStream_t st, const double *d_internal, double *traj,
+                          int64_t n_cols, int64_t col);
 // LDS bytes the resident kernel needs for this plan (0 = it cannot hold it).
 int persistent_lds_bytes(int max_local, int max_owned, int max_items, int max_halo);
 // How many workgroups of the resident kernel can be co-resident on the device (0 on error).

@@ -772,8 +772,19 @@ __global__ void __launch_bounds__(SAA_LB) persistent_steps_kernel(DeviceMesh m, 
     // the state buffers only need the last two steps of the launch (d^n and d^(n-1) for whoever comes next)
     const bool keep = s + 2 >= a.nsteps;
     // new value of owned dof i: state buffer, stamped entry for the neighbouring workgroups, LDS image
+    // trajectory recorder: is this step's result a column of the caller's matrix?
+    double *traj_col = nullptr;
+    int64_t traj_ld = 0;
+    if (ap->traj != nullptr) {
+      const int64_t idx = ap->step_index0 + s, every = ap->save_every;
+      if (idx % every == 0 && idx / every < ap->traj_cols) {
+        traj_col = ap->traj + idx / every;
+        traj_ld = ap->traj_cols;
+      }
+    }
     auto commit = [&](int i, int n, int c, double u, double v) {
       if (keep) gnext[base + i] = v;
+      if (traj_col != nullptr) traj_col[(3 * (int64_t)ap->new_to_old[bd.node_start + n] + c) * traj_ld] = v;
       {
         // one 16-byte store, agent scope (write-through to the level all XCDs share); each half validates itself
         const unsigned long long b = (unsigned long long)__double_as_longlong(v);
@@ -900,6 +911,16 @@ __global__ void unpermute_kernel(int n_nodes, const int32_t *__restrict__ new_to
   if (i < 3 * (int64_t)n_nodes) {
     const int n = (int)(i / 3), c = (int)(i - 3 * (int64_t)n);
     out[3 * (int64_t)new_to_old[n] + c] = in[i];
+  }
+}
+
+// trajectory recorder of the per-step paths: internal-order state -> one column of the caller's (3n, n_cols) matrix
+__global__ void record_column_kernel(int n_nodes, const int32_t *__restrict__ new_to_old, const double *__restrict__ d,
+                                     double *__restrict__ traj, int64_t n_cols, int64_t col) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < 3 * (int64_t)n_nodes) {
+    const int n = (int)(i / 3), c = (int)(i - 3 * (int64_t)n);
+    traj[(3 * (int64_t)new_to_old[n] + c) * n_cols + col] = d[i];
   }
 }
 
@@ -1037,6 +1058,13 @@ void launch_cd_update(const DeviceMesh &m, hipStream_t st, const double *f_int, 
   const int64_t n = 3 * (int64_t)m.n_nodes;
   hipLaunchKernelGGL(cd_update_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, m, f_int, d0, dn,
                      d1, k);
+}
+
+void launch_record_column(int n_nodes, const int32_t *new_to_old, hipStream_t st, const double *d_internal, double *traj,
+                          int64_t n_cols, int64_t col) {
+  const int64_t n = 3 * (int64_t)n_nodes;
+  hipLaunchKernelGGL(record_column_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n_nodes, new_to_old,
+                     d_internal, traj, n_cols, col);
 }
 
 void launch_permute(int n_nodes, const int32_t *new_to_old, hipStream_t st, const double *in, double *out) {

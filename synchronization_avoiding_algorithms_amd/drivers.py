@@ -60,6 +60,25 @@ def make_partition(mesh, world, how="slab"):
     return slab_partition(mesh, world) if how == "slab" else rcb_partition(mesh, world)
 
 
+# Largest trajectory matrix kept on the GPU by the drivers (bytes); beyond it the host collects column by column.
+DEVICE_TRAJECTORY_BUDGET = 32 << 30
+
+
+def _device_recorder(part, n_steps, save_every):
+    """``d1_save`` (``Data_prepare.py:219,236-240``) as a device matrix filled by the step kernels themselves
+    (``saa_set_recorder``), or None when the solver has no recorder / the matrix would not fit the budget."""
+    import torch
+
+    n_cols = int(n_steps / save_every)
+    n_dof = 3 * len(part.layout.nodes)
+    if (part.tensor_device.type != "cuda" or not hasattr(part.solver, "set_recorder") or n_cols <= 0
+            or 8 * n_dof * n_cols > DEVICE_TRAJECTORY_BUDGET):
+        return None
+    traj = torch.zeros((n_dof, n_cols), dtype=torch.float64, device=part.tensor_device)
+    part.solver.set_recorder(traj, save_every, 0)
+    return traj
+
+
 def _saver(part, n_steps, save_every):
     store = np.zeros((3 * len(part.layout.nodes), int(n_steps / save_every)))
     state = {"counter": 0}
@@ -86,13 +105,20 @@ def data_prepare(mesh, n_steps=100000, save_every=1, out_dir=".", rank=0, world=
         rio.save_int_list(os.path.join(out_dir, PATHS["global_shared"]), part.global_shared)
         if verbose:
             print("Time-step size is: " + str(part.dt))
-    store, save = _saver(part, n_steps, save_every)
-    i = 0
-    while i < n_steps:  # saved steps are i % save_every == 0 (Data_prepare.py:238-240)
-        n = 1 if i % save_every == 0 else min(save_every - i % save_every, n_steps - i)
-        part.step_synced(n)
-        i += n
-        save(i - 1, part)
+    traj = _device_recorder(part, n_steps, save_every)
+    if traj is not None:  # the kernels fill the trajectory; the whole run is a handful of launches
+        part.step_synced(n_steps)
+        part.solver.synchronize()
+        store = traj.cpu().numpy()
+        part.solver.set_recorder(None)
+    else:
+        store, save = _saver(part, n_steps, save_every)
+        i = 0
+        while i < n_steps:  # saved steps are i % save_every == 0 (Data_prepare.py:238-240)
+            n = 1 if i % save_every == 0 else min(save_every - i % save_every, n_steps - i)
+            part.step_synced(n)
+            i += n
+            save(i - 1, part)
     path = rio.save_displacement(os.path.join(out_dir, PATHS["truth"].format(r=rank)), store)
     part.close()
     return path, store
@@ -154,10 +180,15 @@ def online_predictor(mesh, n_steps=100000, save_every=1, out_dir=".", rank=0, wo
                                                             ns=filter_size))
         model = pr.call_model(part.tensor_device, filter_size, part.input_size, hidden_size, mpath)
     model = model.to(part.tensor_device)
-    store, save = _saver(part, n_steps, save_every)
+    traj = _device_recorder(part, n_steps, save_every)
+    store, save = (None, None) if traj is not None else _saver(part, n_steps, save_every)
     with torch.no_grad():
         hist = run_hybrid(part, n_steps, pr.DevicePredictor(model, n_past, n_future, filter_size, *scale),
                           n_past, n_future, filter_size, save=save)
+    if traj is not None:
+        part.solver.synchronize()
+        store = traj.cpu().numpy()
+        part.solver.set_recorder(None)
     path = rio.save_displacement(os.path.join(out_dir, PATHS["modeled"].format(r=rank)), store)
     part.close()
     return path, store, hist

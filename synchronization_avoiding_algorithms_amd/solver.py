@@ -109,6 +109,20 @@ class HipExplicitSolver:
         _lib.check(self._lib.saa_resident_kernel_info(self._h, C.byref(cap), C.byref(lds), C.byref(spl)))
         return {"capable": bool(cap.value), "lds_bytes": lds.value, "steps_per_launch": spl.value}
 
+    def set_recorder(self, traj=None, save_every=1, next_step_index=0):
+        """``traj``: float64 CUDA tensor ``(3*n_nodes, n_cols)`` (kept alive by the caller) that receives the
+        displacement of every ``save_every``-th step, like ``d1_save`` of ``Data_prepare.py:236-240``; ``None``
+        switches recording off."""
+        if traj is None:
+            _lib.check(self._lib.saa_set_recorder(self._h, None, 0, 1, 0))
+            self._traj = None
+            return
+        if traj.dim() != 2 or traj.shape[0] != self.n_dof:
+            raise ValueError(f"trajectory matrix must be ({self.n_dof}, n_cols)")
+        _lib.check(self._lib.saa_set_recorder(self._h, _dev(traj), int(traj.shape[1]), int(save_every),
+                                              int(next_step_index)))
+        self._traj = traj
+
     def set_resident_kernel(self, enable: bool):
         _lib.check(self._lib.saa_set_resident_kernel(self._h, 1 if enable else 0))
 

@@ -349,3 +349,38 @@ def test_peer_exchange_inside_the_resident_kernel(monkeypatch):
         assert rel_l2(b, a) < 1e-12
     dof = (3 * shared[:, None] + np.arange(3)[None, :]).ravel()
     assert np.array_equal(out[1][2][144], out[1][0][dof, 0])  # last history row = shared dofs of the final state
+
+
+@pytest.mark.parametrize("save_every", [1, 3])
+def test_trajectory_recorder_matches_stepwise_downloads(save_every):
+    """``saa_set_recorder``: the ground-truth loop's ``d1_save[:, counter] = d1`` (Data_prepare.py:236-240) written by
+    the step kernels (fused per-step launches and the resident kernel alike) against downloading the state after
+    every step."""
+    import torch
+    from synchronization_avoiding_algorithms_amd.mesh import structured_beam
+
+    mesh = structured_beam(5)
+    n_steps = 150
+    ref, _, _, _, _ = _serial_solver(mesh, block_nodes=120, threads=256)
+    want = np.zeros((ref.n_dof, int(n_steps / save_every)))
+    col = 0
+    for i in range(n_steps):
+        ref.step(1)
+        if i % save_every == 0 and col < want.shape[1]:
+            want[:, col] = ref.get_state()[0][:, 0]
+            col += 1
+    ref.close()
+    sol, _, _, _, _ = _serial_solver(mesh, block_nodes=120, threads=256)
+    traj = torch.zeros(want.shape, dtype=torch.float64, device="cuda")
+    sol.set_recorder(traj, save_every, 0)
+    for k in (1, 2, 40, 7, 100):  # 150 steps: single launches, short fused runs, resident launches
+        sol.step(k)
+    sol.synchronize()
+    got = traj.cpu().numpy()
+    assert np.abs(got[:, -1]).max() > 0
+    assert rel_l2(got, want) < 1e-12
+    sol.set_recorder(None)
+    sol.step(10)  # recorder off: the matrix is left alone
+    sol.synchronize()
+    assert np.array_equal(traj.cpu().numpy(), got)
+    sol.close()
