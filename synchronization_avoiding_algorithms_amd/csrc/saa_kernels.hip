@@ -277,17 +277,19 @@ __device__ __forceinline__ void peer_store(PeerEntry *d, double f, unsigned seq)
   // one 16-byte store, system scope (write-through to the peer); each 8-byte half validates itself
   asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(d), "v"(w) : "memory");
 }
-__device__ __forceinline__ void peer_push(const PeerMap &pm, const PeerPushRec &r, int q, int c, double f, unsigned seq) {
+// (the peer map is addressed through a pointer and its fields are read where they are used: a by-value copy costs
+// ~30 scalar registers for the whole tail of the step, and the step kernels have none to spare)
+__device__ __forceinline__ void peer_push(const PeerMap *pm, const PeerPushRec &r, int q, int c, double f, unsigned seq) {
   const int64_t par = seq & 1u;
   const int n_nb = r.info >> 16;
   if (n_nb > 0) peer_store(r.dst0 + par * r.pstride0 + c, f, seq);
   if (n_nb > 1) {  // node held by three or more ranks
-    const int e0 = pm.nb_off[q];
-    for (int e = e0 + 1; e < e0 + n_nb; ++e) peer_store(pm.push_dst[e] + par * pm.push_pstride[e] + c, f, seq);
+    const int e0 = pm->nb_off[q];
+    for (int e = e0 + 1; e < e0 + n_nb; ++e) peer_store(pm->push_dst[e] + par * pm->push_pstride[e] + c, f, seq);
   }
 }
 // One neighbour's value of this step: polls - bounded - until both halves carry the step's sequence number.
-__device__ __forceinline__ double peer_wait(const PeerMap &pm, const PeerEntry *src, unsigned seq) {
+__device__ __forceinline__ double peer_wait(const PeerMap *pm, const PeerEntry *src, unsigned seq) {
   const long long t0 = wall_clock64();
   unsigned long long lo, hi;
   while (true) {
@@ -295,9 +297,10 @@ __device__ __forceinline__ double peer_wait(const PeerMap &pm, const PeerEntry *
     hi = __hip_atomic_load(&src->hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if ((unsigned)(lo >> 32) == seq && (unsigned)(hi >> 32) == seq) break;
     // slow path only: a wait that already failed somewhere in this launch is not repeated for every later value
-    if (__hip_atomic_load(pm.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) break;
-    if (wall_clock64() - t0 > pm.timeout_ticks) {  // a neighbour died or never attached: report, do not hang
-      __hip_atomic_store(pm.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    int32_t *errp = pm->err;
+    if (__hip_atomic_load(errp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) break;
+    if (wall_clock64() - t0 > pm->timeout_ticks) {  // a neighbour died or never attached: report, do not hang
+      __hip_atomic_store(errp, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       break;
     }
     __builtin_amdgcn_s_sleep(2);
@@ -306,18 +309,20 @@ __device__ __forceinline__ double peer_wait(const PeerMap &pm, const PeerEntry *
 }
 // Force of shared node q, component c, summed over the holding ranks in RANK ORDER (the order of syn_cpus,
 // Distributed_tools.py:84-86: identical bits on every rank).
-__device__ __forceinline__ double peer_collect(const PeerMap &pm, const PeerRecvRec &r, int q, int c, double own,
+__device__ __forceinline__ double peer_collect(const PeerMap *pm, const PeerRecvRec &r, int q, int c, double own,
                                                unsigned seq) {
-  const PeerEntry *in = pm.inbox + (int64_t)(seq & 1u) * pm.parity_stride + c;
-  const unsigned long long others = r.holders & ~(1ull << pm.rank);
+  const int rank = pm->rank;
+  const PeerEntry *in = pm->inbox + (int64_t)(seq & 1u) * pm->parity_stride + c;
+  const unsigned long long others = r.holders & ~(1ull << rank);
   if (others == 0ull) return own;  // declared shared, held by this rank only
   if ((others & (others - 1ull)) == 0ull) return own + peer_wait(pm, in + r.recv0, seq);  // one other holder: a + b == b + a
-  int e = pm.nb_off[q];
+  int e = pm->nb_off[q];
+  const int world = pm->world;
   double f = 0.0;
   bool first = true;
-  for (int p = 0; p < pm.world; ++p) {
+  for (int p = 0; p < world; ++p) {
     if (!((r.holders >> p) & 1ull)) continue;
-    const double v = p == pm.rank ? own : peer_wait(pm, in + pm.recv_idx[e++], seq);
+    const double v = p == rank ? own : peer_wait(pm, in + pm->recv_idx[e++], seq);
     f = first ? v : f + v;
     first = false;
   }
@@ -525,15 +530,13 @@ __global__ void __launch_bounds__(SAA_LB) fused_step_kernel(DeviceMesh m, const 
   // (the map is read from device memory HERE, not passed by value: a by-value copy would sit in SGPRs through
   // the element phase, which has none to spare)
   int sh0 = 0, n_sh3 = 0;
-  PeerMap pm{};
   if (PEER) {
-    pm = *pmap;
-    sh0 = pm.blk_off[pblock];
-    n_sh3 = 3 * (pm.blk_off[pblock + 1] - sh0);
+    sh0 = pmap->blk_off[pblock];
+    n_sh3 = 3 * (pmap->blk_off[pblock + 1] - sh0);
     for (int j = tid; j < n_sh3; j += nt) {
       const int q = sh0 + j / 3, c = j % 3;
-      const PeerPushRec r = pm.push_rec[q];
-      peer_push(pm, r, q, c, acc[(r.info & 0xffff) + c * fstride], seq);
+      const PeerPushRec r = pmap->push_rec[q];
+      peer_push(pmap, r, q, c, acc[(r.info & 0xffff) + c * fstride], seq);
     }
   }
   const int n_early3 = 3 * bd.n_early;
@@ -550,13 +553,13 @@ __global__ void __launch_bounds__(SAA_LB) fused_step_kernel(DeviceMesh m, const 
   if (PEER) {
     for (int j = tid; j < n_sh3; j += nt) {
       const int q = sh0 + j / 3, c = j % 3;
-      const PeerRecvRec r = pm.recv_rec[q];
-      const int n = pm.push_rec[q].info & 0xffff, node = bd.node_start + n;
+      const PeerRecvRec r = pmap->recv_rec[q];
+      const int n = pmap->push_rec[q].info & 0xffff, node = bd.node_start + n;
       const int64_t g = 3 * (int64_t)node + c;
       // operands first: their latency overlaps the poll
       const double fe = m.fext[g], ma = m.mass[g], dnv = dn[g];
       const int32_t tag = m.tag[node];
-      const double f = peer_collect(pm, r, q, c, acc[n + c * fstride], seq);
+      const double f = peer_collect(pmap, r, q, c, acc[n + c * fstride], seq);
       double v = cd_update_dof(f, fe, ma, rec[6 * n + 3 + c], dnv, k);  // Dynamic_solver.py:26-32
       if (tag & (1 << c)) v = 0.0;
       out[g] = v;
@@ -586,10 +589,10 @@ template __global__ void fused_step_kernel<false, 0, true>(DeviceMesh, const dou
 __global__ void peer_selftest_kernel(PeerMap pm, const double *__restrict__ own, double *__restrict__ out,
                                      unsigned seq) {
   const int gtid = blockIdx.x * blockDim.x + threadIdx.x, gthreads = gridDim.x * blockDim.x;
-  for (int j = gtid; j < 3 * pm.n_shared; j += gthreads) peer_push(pm, pm.push_rec[j / 3], j / 3, j % 3, own[j], seq);
+  for (int j = gtid; j < 3 * pm.n_shared; j += gthreads) peer_push(&pm, pm.push_rec[j / 3], j / 3, j % 3, own[j], seq);
   for (int j = gtid; j < 3 * pm.n_shared; j += gthreads) {
     const PeerRecvRec r = pm.recv_rec[j / 3];
-    out[3 * (int64_t)r.sidx + j % 3] = peer_collect(pm, r, j / 3, j % 3, own[j], seq);
+    out[3 * (int64_t)r.sidx + j % 3] = peer_collect(&pm, r, j / 3, j % 3, own[j], seq);
   }
 }
 
@@ -799,15 +802,14 @@ __global__ void __launch_bounds__(SAA_LB) persistent_steps_kernel(DeviceMesh m, 
     // collected after the update of the other nodes (the xGMI flight time hides under it)
     int sh0 = 0, n_sh3 = 0;
     unsigned pseq = 0;
-    PeerMap pm{};
     if (PEER) {
-      pm = *ap->peer;
+      const PeerMap *pm = ap->peer;
       pseq = ap->peer_seq_base + (unsigned)s + 1u;  // the host keeps a launch clear of the wrap to 0 ("never written")
-      sh0 = pm.blk_off[pblock];
-      n_sh3 = 3 * (pm.blk_off[pblock + 1] - sh0);
+      sh0 = pm->blk_off[pblock];
+      n_sh3 = 3 * (pm->blk_off[pblock + 1] - sh0);
       for (int j = ltid; j < n_sh3; j += nt) {
         const int q = sh0 + j / 3, c = j % 3;
-        const PeerPushRec r = pm.push_rec[q];
+        const PeerPushRec r = pm->push_rec[q];
         peer_push(pm, r, q, c, acc[(r.info & 0xffff) + c * fstride], pseq);
       }
     }
@@ -827,10 +829,11 @@ __global__ void __launch_bounds__(SAA_LB) persistent_steps_kernel(DeviceMesh m, 
       commit(i, n, c, u, v);
     }
     if (PEER) {
+      const PeerMap *pm = ap->peer;
       for (int j = ltid; j < n_sh3; j += nt) {
         const int q = sh0 + j / 3, c = j % 3;
-        const PeerRecvRec r = pm.recv_rec[q];
-        const int n = pm.push_rec[q].info & 0xffff, i = 3 * n + c;
+        const PeerRecvRec r = pm->recv_rec[q];
+        const int n = pm->push_rec[q].info & 0xffff, i = 3 * n + c;
         const double f = peer_collect(pm, r, q, c, acc[n + c * fstride], pseq);
         const double u = rec[6 * n + 3 + c];
         double v = cd_update_dof(f, c == 0 ? 0.0 : fextl[n], massl[n], u, dnl[i], k);  // Dynamic_solver.py:26-32
