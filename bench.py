@@ -3,10 +3,12 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-One *step* = one explicit time step of the whole mesh (fused HIP kernel per partition; for N > 1 a
-per-step all-reduce of the shared-node forces over RCCL).  N = 1 runs BASELINE.json configs[2]
-(the ~1M-tet beam, one partition); N > 1 keeps ~1M tets per GPU (weak scaling; N = 8 is configs[3],
-the ~8M-tet beam in 8 slabs).  Rank 0 prints ONE JSON line.
+One *step* = one explicit time step of the whole mesh (per partition: the resident multi-step kernel, or one fused
+kernel per step; for N > 1 the forces of the shared nodes are summed across ranks every step - by direct xGMI peer
+stores inside the step kernel when that path proves itself in a child-process preflight, else by an RCCL all-reduce;
+with the peer exchange in use the RCCL variant is measured too and reported as `rccl_allreduce`).  N = 1 runs
+BASELINE.json configs[2] (the ~1M-tet beam, one partition); N > 1 keeps ~1M tets per GPU (weak scaling; N = 8 is
+configs[3], the ~8M-tet beam in 8 slabs; `sync_avoiding` = configs[4]).  Rank 0 prints ONE JSON line.
 
 Extra objects on the N = 1 line:
   roofline      algorithmic bytes/step (16*Ne + 216*Nn) / HIP-event time of the fused
@@ -165,6 +167,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="process-group backend for N > 1 (nccl = RCCL)")
     ap.add_argument("--no-sync-avoiding", action="store_true", help="N > 1: skip the sync-avoiding-mode leg")
+    ap.add_argument("--no-rccl-leg", action="store_true",
+                    help="N > 1: skip the extra measurement with the RCCL all-reduce when the peer exchange is in use")
     ap.add_argument("--torch-exchange", action="store_true",
                     help="N > 1: all-reduce through torch.distributed (same as --exchange torch)")
     ap.add_argument("--exchange", default="auto", choices=["auto", "peer", "rccl", "torch"],
@@ -357,6 +361,39 @@ def main():
         if not args.no_cpu_baseline:
             out["cpu_baseline"], out["parity"] = cpu_baseline_and_parity()
     sol.close()
+    # N > 1: BASELINE.json configs[3] names the RCCL all-reduce as the per-step exchange.  When `value` above was
+    # measured with the peer exchange, the same partitions are stepped once more with ncclAllReduce issued from C++
+    # (saa_step_synced) and reported next to it.
+    if world > 1 and part.exchange == "peer" and args.backend == "nccl" and not args.same_device and not args.no_rccl_leg:
+        import threading
+
+        leg_done = threading.Event()
+
+        def watchdog():  # this leg must never cost the headline line: after 4 minutes print what there is and leave
+            if not leg_done.wait(240):
+                if rank == 0:
+                    out["rccl_allreduce"] = {"value": None, "exchange": "timed out"}
+                    print(json.dumps(out), flush=True)
+                os._exit(0)
+
+        threading.Thread(target=watchdog, daemon=True).start()
+        k_r, w_r = min(args.steps, 2000), min(args.warmup, 200)
+        args_steps, args_warmup = args.steps, args.warmup
+        args.steps, args.warmup = k_r, w_r
+        try:
+            part_r, elapsed_r, ok_r = build_and_time("rccl")
+            how = part_r.exchange
+            part_r.close()
+        except Exception as e:  # noqa: BLE001 - reported, never fatal for the headline line
+            ok_r, how, elapsed_r = False, f"failed: {e}"[:200], float("nan")
+        args.steps, args.warmup = args_steps, args_warmup
+        if rank == 0:
+            out["rccl_allreduce"] = ({"value": ne_total * k_r / elapsed_r, "unit": "element-updates/s",
+                                      "ms_per_step": 1e3 * elapsed_r / k_r, "steps": k_r, "warmup": w_r, "exchange": how,
+                                      "note": "same partitions; shared-node forces summed by an all-reduce of "
+                                              f"{3 * len(gshared)} doubles every step instead of the peer exchange"}
+                                     if ok_r else {"value": None, "exchange": how})
+        leg_done.set()
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
