@@ -364,7 +364,8 @@ def main():
     # N > 1: BASELINE.json configs[3] names the RCCL all-reduce as the per-step exchange.  When `value` above was
     # measured with the peer exchange, the same partitions are stepped once more with ncclAllReduce issued from C++
     # (saa_step_synced) and reported next to it.
-    if world > 1 and part.exchange == "peer" and args.backend == "nccl" and not args.same_device and not args.no_rccl_leg:
+    leg_ok = (args.backend == "nccl" and not args.same_device) or bool(os.environ.get("SAA_BENCH_FORCE_RCCL_LEG"))
+    if world > 1 and part.exchange == "peer" and leg_ok and not args.no_rccl_leg:
         import threading
 
         leg_done = threading.Event()
@@ -381,7 +382,7 @@ def main():
         args_steps, args_warmup = args.steps, args.warmup
         args.steps, args.warmup = k_r, w_r
         try:
-            part_r, elapsed_r, ok_r = build_and_time("rccl")
+            part_r, elapsed_r, ok_r = build_and_time("rccl" if args.backend == "nccl" else "torch")
             how = part_r.exchange
             part_r.close()
         except Exception as e:  # noqa: BLE001 - reported, never fatal for the headline line
