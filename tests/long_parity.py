@@ -10,7 +10,7 @@ from bench import build_rank_solver  # noqa: E402
 from oracle import fem_oracle as fo  # noqa: E402
 from synchronization_avoiding_algorithms_amd.mesh import Mesh  # noqa: E402
 
-g = np.load(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "beam_coarse_mesh.npz"))
+g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "beam_coarse_mesh.npz"))
 mesh = Mesh(g["points"], {"tetra": g["tetra"], "triangle": g["triangle"]})
 ranks, dt, _, _ = fo.setup_problem(mesh.points, mesh.tets, mesh.triangles, 1, np.zeros(len(mesh.tets), dtype=int))
 sol, lay, _, gdt = build_rank_solver(mesh, 1, 0, 0)
