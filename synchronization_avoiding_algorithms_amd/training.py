@@ -49,14 +49,67 @@ def _decode(model, X, n_future):
     return torch.stack(outs, dim=1)
 
 
-def model_train(device, model, batches, criterion, optimizer, n_future):
+class GraphedTrainStep:
+    """One optimiser step (decode, loss, backward, Adam, running sums) captured as a HIP graph.
+
+    The step is ~1300 kernels of a few microseconds each: launched one by one from Python the GPU idles most of the
+    time (13 ms per step at input size 24), replayed as a graph it takes 4 ms.  The first ``warmup`` full batches of
+    the first epoch run eagerly on a side stream (they are ordinary training steps), then the step is captured once
+    and replayed for every later full batch; a trailing partial batch runs eagerly.  Needs an optimiser built with
+    ``capturable=True`` and a tensor learning rate (so that the scheduler's updates reach the replays)."""
+
+    def __init__(self, model, criterion, optimizer, n_future, batch_shape_x, batch_shape_y, device, warmup=3):
+        self.model, self.criterion, self.optimizer, self.n_future = model, criterion, optimizer, n_future
+        self.X = torch.zeros(batch_shape_x, dtype=torch.float32, device=device)
+        self.Y = torch.zeros(batch_shape_y, dtype=torch.float32, device=device)
+        self.sums = torch.zeros(3, dtype=torch.float64, device=device)
+        self.graph, self.seen, self.warmup = None, 0, warmup
+        self.side = torch.cuda.Stream(device=device)
+
+    def _step(self):
+        self.optimizer.zero_grad(set_to_none=True)
+        loss = self.criterion(_decode(self.model, self.X, self.n_future), self.Y)
+        with torch.no_grad():
+            self.sums[1] += (1.0 - loss / self.criterion(self.Y, torch.mean(self.Y) + torch.zeros_like(self.Y))).double()
+            self.sums[2] += (1.0 - loss / self.criterion(self.Y, torch.zeros_like(self.Y))).double()
+            self.sums[0] += loss.detach().double()
+        loss.backward()
+        self.optimizer.step()
+
+    def run(self, X, Y):
+        self.X.copy_(X)
+        self.Y.copy_(Y)
+        if self.graph is not None:
+            self.graph.replay()
+            return
+        if self.seen < self.warmup:  # eager, on a side stream as graph capture wants its warm-up
+            self.side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.side):
+                self._step()
+            torch.cuda.current_stream().wait_stream(self.side)
+            self.seen += 1
+            return
+        graph = torch.cuda.CUDAGraph()
+        self.optimizer.zero_grad(set_to_none=True)
+        with torch.cuda.graph(graph):
+            self._step()
+        self.graph = graph
+        self.graph.replay()  # capture does not execute: this is the step for the batch just copied in
+
+
+def model_train(device, model, batches, criterion, optimizer, n_future, graphed=None):
     """One epoch of recursive-decoding training (``DNN_tools.py:103-165``, 'recursive' method).
     Returns (sum of batch losses, sum of R2 accuracies, sum of relative accuracies, model)."""
     model.train()
     # the three running sums stay on the device (float64, like the reference's Python floats) and come back once per
     # epoch: a .item() per batch would stall the launch-bound GPU three times per optimiser step
     sums = torch.zeros(3, dtype=torch.float64, device=device)
+    if graphed is not None:
+        graphed.sums.zero_()
     for X, Y in batches:
+        if graphed is not None and X.shape == graphed.X.shape:
+            graphed.run(X, Y)
+            continue
         optimizer.zero_grad()
         out = _decode(model, X, n_future)
         loss = criterion(out, Y)
@@ -66,6 +119,8 @@ def model_train(device, model, batches, criterion, optimizer, n_future):
             sums[0] += loss.detach().double()
         loss.backward()
         optimizer.step()
+    if graphed is not None:
+        sums += graphed.sums
     loss_sum, r2_sum, rel_sum = sums.tolist()
     return loss_sum, r2_sum, rel_sum, model
 
@@ -109,7 +164,11 @@ def train_rank_model(out_dir=".", rank=0, device=None, batch_size=10, learning_r
     X, Y, _, _ = scale_to_zero_one(X, Y)
     model = LSTM_encoder_decoder(input_size, hidden_size, 2, True, 0.0, 0.0).to(device)
     criterion = nn.MSELoss()
-    optimizer = torch.optim.Adam(model.parameters(), lr=learning_rate)
+    use_graph = device.type == "cuda" and os.environ.get("SAA_TRAIN_GRAPH", "1") != "0"
+    if use_graph:  # capturable Adam with a tensor learning rate: the scheduler's updates reach the graph replays
+        optimizer = torch.optim.Adam(model.parameters(), lr=torch.tensor(learning_rate, device=device), capturable=True)
+    else:
+        optimizer = torch.optim.Adam(model.parameters(), lr=learning_rate)
     scheduler = torch.optim.lr_scheduler.LambdaLR(optimizer, lr_lambda=lambda epoch: decay ** epoch)
     if num_epochs is None:
         num_epochs = int(math.log(lr_min / learning_rate, decay))     # Model_training.py:65
@@ -119,16 +178,20 @@ def train_rank_model(out_dir=".", rank=0, device=None, batch_size=10, learning_r
     Xtr, Ytr = X[torch.as_tensor(train_idx, device=device)], Y[torch.as_tensor(train_idx, device=device)]
     Xte, Yte = X[torch.as_tensor(test_idx, device=device)], Y[torch.as_tensor(test_idx, device=device)]
     train_loss, test_loss = [], []
+    graphed = None
+    if use_graph and Xtr.shape[0] >= batch_size:
+        graphed = GraphedTrainStep(model, criterion, optimizer, n_future, (batch_size,) + tuple(Xtr.shape[1:]),
+                                   (batch_size,) + tuple(Ytr.shape[1:]), device)
     for epoch in range(num_epochs):
         tb = _batches(Xtr, Ytr, batch_size, True, gen)
         vb = _batches(Xte, Yte, batch_size, False)
-        lt, r2, _, model = model_train(device, model, tb, criterion, optimizer, n_future)
+        lt, r2, _, model = model_train(device, model, tb, criterion, optimizer, n_future, graphed)
         lv, _, _ = model_test(device, model, vb, criterion, n_future) if vb else (float("nan"), 0, 0)
         train_loss.append(lt / len(tb))
         test_loss.append(lv / max(len(vb), 1))
         if verbose and rank == 0 and epoch % 50 == 0:
             print("Epoch: %d, mse training loss: %1.5e, R2 accuracy: %.3f, lr=%g"
-                  % (epoch, train_loss[-1], r2 / len(tb), optimizer.param_groups[0]["lr"]))
+                  % (epoch, train_loss[-1], r2 / len(tb), float(optimizer.param_groups[0]["lr"])))
         scheduler.step()
     path = os.path.join(out_dir, PATHS["model"].format(r=rank, nB=batch_size, nH=hidden_size, lr=learning_rate,
                                                        ns=filter_size))

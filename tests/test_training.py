@@ -43,3 +43,30 @@ def test_training_reduces_loss_and_writes_reference_layout(tmp_path):
     # a (briefly) trained model tracks the smooth signal far better than the mean would
     err = (table - hist[400:430]).abs().max().item()
     assert err < 0.5 * (smax - smin)
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_graph_captured_training_step_matches_eager_training(tmp_path, monkeypatch):
+    """On the GPU the optimiser step is replayed as a HIP graph (GraphedTrainStep): same seeds, same batches, same
+    learning-rate schedule as eager training -> the same losses up to fp32 run-to-run noise."""
+    traj = _fake_shared_trajectory(n_in=12, n_steps=4000)
+    losses, paths = [], []
+    for mode in ("0", "1"):
+        out = str(tmp_path / f"graph{mode}")
+        rio.save_int_list(os.path.join(out, drivers.PATHS["shared"].format(r=0)), [3, 9, 11, 17])
+        rio.save_displacement(os.path.join(out, drivers.PATHS["shared_traj"].format(r=0)), traj, compress=False)
+        monkeypatch.setenv("SAA_TRAIN_GRAPH", mode)
+        path, train_loss, test_loss = tr.train_rank_model(out, 0, device="cuda", hidden_size=8, filter_size=10, n_past=4,
+                                                          n_future=3, num_epochs=12, learning_rate=5e-3, seed=0)
+        losses.append((np.array(train_loss), np.array(test_loss)))
+        paths.append(path)
+    (tl0, vl0), (tl1, vl1) = losses
+    assert tl1[-1] < 0.5 * tl1[0]
+    assert np.allclose(tl1, tl0, rtol=2e-2) and np.allclose(vl1, vl0, rtol=2e-2)
+    a, b = torch.load(paths[0], weights_only=True), torch.load(paths[1], weights_only=True)
+    assert a.keys() == b.keys()
+    for k in a:
+        assert torch.allclose(a[k], b[k], rtol=0, atol=5e-3), k
