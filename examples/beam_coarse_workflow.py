@@ -31,6 +31,10 @@ def main():
     ap.add_argument("--backend", default="nccl")
     ap.add_argument("--same-device", action="store_true")
     args = ap.parse_args()
+    if args.same_device:
+        # ranks sharing one GPU: graph replays of two processes on one device get in each other's way (2x slower than
+        # eager launches); with one GPU per rank the graphed optimiser step is 3.7x faster and stays on
+        os.environ.setdefault("SAA_TRAIN_GRAPH", "0")
 
     import torch
     import torch.distributed as dist
