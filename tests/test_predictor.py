@@ -39,3 +39,32 @@ def test_model_predict_single_equals_batched():
     X = torch.randn(5, 6, 9)
     one = torch.stack([pr.model_predict("cpu", model, X[i], 4) for i in range(5)])
     assert torch.allclose(one, pr.model_predict("cpu", model, X, 4), atol=1e-6)
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_device_predictor_graph_replay_equals_eager_calls():
+    """DevicePredictor replays the per-window prediction as a HIP graph after two eager calls; the window position
+    is a device scalar, so one capture serves every window."""
+    import torch
+
+    from synchronization_avoiding_algorithms_amd import predictor as pr
+
+    torch.manual_seed(3)
+    dev = torch.device("cuda")
+    n_p, n_f, n_s, insz = 4, 3, 10, 18
+    model = pr.LSTM_encoder_decoder(insz, 8).to(dev).eval()
+    hist = torch.randn(400, insz, dtype=torch.float64, device=dev) * 1e-3
+    p = pr.DevicePredictor(model, n_p, n_f, n_s, 2e-3, -2e-3)
+    with torch.no_grad():
+        for n in (40, 70, 100, 133, 260, 41):
+            got = p(n, hist).clone()
+            want = pr.predict_table(model, n, n_p, n_f, n_s, hist, 2e-3, -2e-3)
+            assert torch.allclose(got, want, rtol=1e-6, atol=1e-12), n
+        assert p._graph is not None  # the later calls were replays
+        other = hist.clone()         # a different history tensor: captured again, still right
+        for n in (50, 90, 120, 200):
+            assert torch.allclose(p(n, other), pr.predict_table(model, n, n_p, n_f, n_s, other, 2e-3, -2e-3),
+                                  rtol=1e-6, atol=1e-12)
