@@ -118,10 +118,12 @@ def test_two_rank_hybrid_loop_matches_reference(tmp_path):
         assert rel_l2(got["hist"], h[f"r{r}_d_sol_shared"]) < 1e-5
 
 
-def _three_rank_worker(rank, world, port, out_dir, use_gpu, exchange="auto"):
+def _three_rank_worker(rank, world, port, out_dir, use_gpu, exchange="auto", force_resident=False):
     sys.path.insert(0, REPO)
     sys.path.insert(0, os.path.join(REPO, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if force_resident:  # ranks share the test GPU: keep the resident kernel on anyway (that is what is under test)
+        os.environ.update(SAA_FORCE_RESIDENT="1", SAA_PEER_TIMEOUT_S="20")
     if use_gpu:
         torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -147,13 +149,13 @@ def _t_partition(mesh):
     return np.where(c[:, 0] < 2.0, 0, np.where(c[:, 1] < 0.5, 1, 2)).astype(np.int64)
 
 
-def _check_three_ranks(tmp_path, use_gpu, exchange="auto"):
+def _check_three_ranks(tmp_path, use_gpu, exchange="auto", force_resident=False):
     from oracle import fem_oracle as fo
     from synchronization_avoiding_algorithms_amd import fem_setup as fs
     from synchronization_avoiding_algorithms_amd.mesh import clamp_nodes, structured_beam
 
     port = free_port()
-    mp.spawn(_three_rank_worker, args=(3, port, str(tmp_path), use_gpu, exchange), nprocs=3, join=True)
+    mp.spawn(_three_rank_worker, args=(3, port, str(tmp_path), use_gpu, exchange, force_resident), nprocs=3, join=True)
     mesh = structured_beam(3, length=4.0)
     layouts, gshared = fs.build_layouts(mesh.tets, _t_partition(mesh), 3, len(mesh.points), clamp_nodes(mesh))
     member = np.zeros(len(mesh.points), dtype=int)

@@ -219,6 +219,15 @@ def test_three_ranks_on_one_gpu_equal_serial(tmp_path, exchange):
     _check_three_ranks(tmp_path, use_gpu=True, exchange=exchange)
 
 
+def test_three_ranks_resident_kernel_with_triple_owned_nodes(tmp_path):
+    """The PEER variant of the resident kernel where some nodes have three holders (two pushes per node, three-term
+    rank-ordered sums) and the holders are three processes."""
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from test_distributed_gloo import _check_three_ranks
+
+    _check_three_ranks(tmp_path, use_gpu=True, exchange="peer", force_resident=True)
+
+
 def _resident_peer_worker(rank, world, port, out_dir):
     sys.path.insert(0, REPO)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0",
