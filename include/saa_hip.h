@@ -80,7 +80,7 @@ typedef struct saa_plan_stats {
 } saa_plan_stats;
 
 const char *saa_last_error(void);
-/* Library / ABI version; bumps when this header changes (2: peer exchange and resident-kernel entry points). */
+/* Library / ABI version; bumps when this header changes (2: peer exchange and resident-kernel entry points; 3: loop-back attach). */
 int32_t saa_abi_version(void);
 
 /* Build the device-resident solver for one partition.  Replaces, for this path,
@@ -173,6 +173,14 @@ int saa_peer_export(saa_solver *s, int32_t world, uint8_t handle_out[64], int32_
 int saa_peer_attach(saa_solver *s, int32_t rank, int32_t world, const uint8_t *handles, const int32_t *devices,
                     const int32_t *slot_counts, const int32_t *slots, const int32_t *orders);
 int saa_peer_selftest(saa_solver *s, int32_t *ok);
+/* Single-GPU rehearsal of the peer exchange (instead of saa_peer_export + saa_peer_attach): this handle becomes rank 0
+ * of `world` (2..8) ranks whose other members are imaginary - they hold exactly this rank's shared nodes and their
+ * inbox segments live in this rank's own inbox, so every pushed value comes straight back.  saa_step_peer then runs the
+ * complete push / stamp / poll / rank-ordered-sum path of a real multi-GPU step with local instead of xGMI latency, and
+ * the force a shared node is updated with is exactly world x its local partial force (a + a + ... in rank order) - a
+ * well-defined operator the parity tests reproduce on the CPU (tests/test_gpu_fullsize.py: the per-GPU workload of the
+ * 8-GPU configuration checked on one GPU).  Needs n_shared > 0. */
+int saa_peer_attach_loopback(saa_solver *s, int32_t world);
 int saa_step_peer(saa_solver *s, int32_t nsteps, double *hist_dev, int64_t hist_row0);
 
 /* nsteps sync-free steps of the predicted phase (Online_predictor.py:287-316): after each local

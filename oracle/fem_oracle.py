@@ -96,11 +96,13 @@ def element_stiffness(P, lmd, mu):
     grad, detJ = physical_gradients(P)
     B = b_matrices(grad)
     D = elasticity_D(lmd, mu)
-    BtDB = np.einsum("eaki,kl,eblj->eaibj", B, D, B)  # (ne,4,3,4,3)
+    # all sixteen blocks (Bi^T D) Bj at once: B as (ne,6,12) with column 3a+i, same association as :112
+    Bf = np.ascontiguousarray(B.transpose(0, 2, 1, 3)).reshape(-1, 6, 12)
+    BtDB = np.matmul(np.matmul(Bf.transpose(0, 2, 1), D), Bf)  # (ne,12,12)
     K = np.zeros_like(BtDB)
     for w in QUAD_WEIGHTS:
-        K += BtDB * detJ[:, None, None, None, None] * w
-    return K.reshape(-1, 12, 12)
+        K += BtDB * detJ[:, None, None] * w
+    return K
 
 
 def element_mass_force(P, rho, fz):
@@ -167,6 +169,51 @@ def assemble_local_stiffness(local_node_list, cells, points, lmd, mu):
     K = csr_matrix((vals, (ukey // (3 * n), ukey % (3 * n))), shape=(3 * n, 3 * n))
     K.sort_indices()
     return K
+
+
+class MatrixFreeStiffness:
+    """``LocalK`` for meshes whose assembled matrix is too expensive to build on the test host (1M tets: 148 M COO
+    triplets): the same element matrices ``Local_K_coronary`` produces (Mat_construction.py:79-119, via
+    :func:`element_stiffness`), kept per element and applied as ``sum_e scatter(K_e . gather(d))`` - what
+    ``Local_assembly_for_stiffness`` (:122-150) followed by ``LocalK.dot`` (Dynamic_solver.py:12) computes, with the
+    additions re-associated (per element first, then over the elements around a dof in element order).  Pinned to
+    the reference's own ``LocalK.dot(d)`` on beam_coarse in ``tests/test_oracle_golden.py``.
+
+    ``cells_local``: (ne,4) node ids in the numbering of ``points_local``; 1.15 kB per element.
+    """
+
+    def __init__(self, cells_local, points_local, lmd, mu, chunk=65536, threads=None):
+        import os
+        from concurrent.futures import ThreadPoolExecutor
+
+        cells = np.asarray(cells_local, dtype=np.int64)
+        pts = np.asarray(points_local, dtype=np.float64)
+        self.n_dof = 3 * len(pts)
+        self.dof = (3 * cells[:, :, None] + np.arange(3)[None, None, :]).reshape(-1, 12)
+        self.Ke = np.empty((len(cells), 12, 12))
+        self.shape = (self.n_dof, self.n_dof)
+        # element ranges are independent; NumPy releases the GIL inside its loops.  The partial vectors of the
+        # ranges are added in range order, so the result does not depend on thread timing.
+        self._pool = ThreadPoolExecutor(max(1, min(threads or 8, os.cpu_count() or 1)))
+        self._ranges = [(lo, min(lo + chunk, len(cells))) for lo in range(0, len(cells), chunk)]
+
+        def fill(r):
+            self.Ke[r[0]:r[1]] = element_stiffness(pts[cells[r[0]:r[1]]], lmd, mu)
+
+        list(self._pool.map(fill, self._ranges))
+
+    def dot(self, d):
+        d = np.asarray(d, dtype=np.float64).reshape(-1)
+
+        def part(r):
+            dof = self.dof[r[0]:r[1]]
+            fe = np.matmul(self.Ke[r[0]:r[1]], d[dof][:, :, None])[:, :, 0]
+            return np.bincount(dof.ravel(), weights=fe.ravel(), minlength=self.n_dof)
+
+        out = np.zeros(self.n_dof)
+        for p in self._pool.map(part, self._ranges):
+            out += p
+        return out.reshape(-1, 1)
 
 
 def lumped_mass_and_load(cells, points, rho, fz):

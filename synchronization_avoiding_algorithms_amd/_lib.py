@@ -13,10 +13,14 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("SAA_LIB_PATH") or os.path.join(_HERE, "libsaa_hip.so")  # override: experiments only
+#: diagnostic build (-DSAA_DIAGNOSTICS: ablated step kernels, in-kernel stamps, saa_debug_* exports) used by tools/
+#: only; built on request (``build_library(diag=True)``), loaded through SAA_LIB_PATH, never by the package itself
+DIAG_LIB_PATH = os.path.join(_HERE, "libsaa_hip_diag.so")
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "saa_hip.h")
 SOURCES = ["saa_plan.cpp", "saa_kernels.hip", "saa_api.cpp"]
 HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics", "-ldl"]
 
+ABI_VERSION = 3  # what saa_abi_version() of a matching library returns (include/saa_hip.h)
 SAA_OK, SAA_E_ARG, SAA_E_HIP, SAA_E_STATE, SAA_E_CAPACITY = 0, -1, -2, -3, -4
 
 
@@ -85,6 +89,7 @@ SIGNATURES = {
     "saa_peer_attach": (C.c_int, [_H, C.c_int32, C.c_int32, C.POINTER(C.c_uint8), C.POINTER(C.c_int32),
                                   C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "saa_peer_selftest": (C.c_int, [_H, C.POINTER(C.c_int32)]),
+    "saa_peer_attach_loopback": (C.c_int, [_H, C.c_int32]),
     "saa_step_peer": (C.c_int, [_H, C.c_int32, C.c_void_p, C.c_int64]),
     "saa_step_predicted": (C.c_int, [_H, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]),
     "saa_halo_gather": (C.c_int, [_H, C.c_void_p]),
@@ -104,21 +109,24 @@ def needs_build() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_library(force: bool = False, verbose: bool = False) -> str:
-    """Compile the HIP sources for gfx950 into ``libsaa_hip.so`` next to this file (in-tree)."""
-    if not force and not needs_build():
-        return LIB_PATH
+def build_library(force: bool = False, verbose: bool = False, diag: bool = False, extra_flags=()) -> str:
+    """Compile the HIP sources for gfx950 into ``libsaa_hip.so`` next to this file (in-tree).  ``diag=True`` builds
+    the diagnostic variant ``libsaa_hip_diag.so`` instead (tools/ only)."""
+    out = DIAG_LIB_PATH if diag else LIB_PATH
+    if not force and not diag and not needs_build():
+        return out
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: libsaa_hip.so cannot be built")
-    cmd = [hipcc, *HIPCC_FLAGS, "saa_plan.cpp", "saa_kernels.hip", "-x", "hip", "saa_api.cpp", "-o", LIB_PATH + ".tmp"]
+    flags = [*HIPCC_FLAGS, *(["-DSAA_DIAGNOSTICS"] if diag else []), *extra_flags]
+    cmd = [hipcc, *flags, *SOURCES[:2], "-x", "hip", SOURCES[2], "-o", out + ".tmp"]
     res = subprocess.run(cmd, cwd=_CSRC, capture_output=True, text=True)
     if res.returncode != 0:
         raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + res.stderr)
     if verbose and res.stderr:
         print(res.stderr)
-    os.replace(LIB_PATH + ".tmp", LIB_PATH)
-    return LIB_PATH
+    os.replace(out + ".tmp", out)
+    return out
 
 
 def load():
@@ -139,6 +147,10 @@ def load():
         except ImportError:
             pass
     lib = C.CDLL(LIB_PATH)
+    lib.saa_abi_version.restype = C.c_int32
+    if lib.saa_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"{LIB_PATH} has ABI version {lib.saa_abi_version()}, this package needs {ABI_VERSION}: "
+                           "rebuild it (`python -c 'import __graft_entry__ as g; g.build()'`)")
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.restype = res

@@ -425,7 +425,7 @@ extern "C" {
 
 const char *saa_last_error(void) { return g_last_error.c_str(); }
 
-int32_t saa_abi_version(void) { return 2; }  // 2: peer exchange and resident-kernel entry points added
+int32_t saa_abi_version(void) { return 3; }  // 2: peer exchange and resident kernel; 3: saa_peer_attach_loopback
 
 int saa_plan_host_stats(int32_t n_nodes, int32_t n_elems, const double *xyz, const int32_t *tets,
                         int32_t block_nodes, saa_plan_stats *out) {
@@ -928,17 +928,31 @@ static int peer_attach_impl(saa_solver *s, int32_t rank, int32_t world, const ui
     if (!loopback) {
       hipIpcMemHandle_t h;
       std::memcpy(&h, handles + 64 * static_cast<size_t>(p), 64);
+      std::string access = "same device";
       if (devices[p] != s->device) {
         int can = 0;
-        (void)hipDeviceCanAccessPeer(&can, s->device, devices[p]);
-        if (can) (void)hipDeviceEnablePeerAccess(devices[p], 0);  // "already enabled" is fine; the self-test decides
+        const hipError_t ce = hipDeviceCanAccessPeer(&can, s->device, devices[p]);
+        access = std::string("hipDeviceCanAccessPeer(") + std::to_string(s->device) + "," + std::to_string(devices[p]) +
+                 ") = " + (ce == hipSuccess ? std::to_string(can) : std::string(hipGetErrorString(ce)));
+        if (ce == hipSuccess && can) {
+          const hipError_t pe = hipDeviceEnablePeerAccess(devices[p], 0);  // "already enabled" is fine
+          access += std::string(", hipDeviceEnablePeerAccess: ") + hipGetErrorString(pe);
+          if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) {
+            (void)hipGetLastError();
+            return fail(SAA_E_HIP, "saa_peer_attach: rank " + std::to_string(p) + ": " + access);
+          }
+        } else if (ce != hipSuccess || !can) {
+          (void)hipGetLastError();
+          return fail(SAA_E_HIP, "saa_peer_attach: no peer access to the device of rank " + std::to_string(p) + ": " + access);
+        }
         (void)hipGetLastError();
       }
       base = nullptr;
       const hipError_t oe = hipIpcOpenMemHandle(&base, h, hipIpcMemLazyEnablePeerAccess);
       if (oe != hipSuccess || !base) {
         (void)hipGetLastError();
-        return fail(SAA_E_HIP, "saa_peer_attach: hipIpcOpenMemHandle(rank " + std::to_string(p) + "): " + hipGetErrorString(oe));
+        return fail(SAA_E_HIP, "saa_peer_attach: hipIpcOpenMemHandle(rank " + std::to_string(p) + "): " +
+                                   hipGetErrorString(oe) + " (" + access + ")");
       }
       s->peer_open.push_back(base);
     }
@@ -1179,8 +1193,9 @@ int saa_time_steps(saa_solver *s, int32_t nsteps, double *elapsed_ms) {
   return rc;
 }
 
-// Diagnostic, not part of include/saa_hip.h: time `nsteps` launches of an ablated step kernel
-// (state is not rotated; outputs are meaningless).  Used by tools/ablate.py only.
+#ifdef SAA_DIAGNOSTICS
+// Diagnostic build only (libsaa_hip_diag.so, -DSAA_DIAGNOSTICS; never in the product library): time `nsteps`
+// launches of an ablated step kernel (state is not rotated; outputs are meaningless).  Used by tools/ablate.py only.
 int saa_debug_time_ablated(saa_solver *s, int32_t variant, int32_t nsteps, double *elapsed_ms) {
   if (!s || !elapsed_ms) return fail(SAA_E_ARG, "saa_debug_time_ablated: bad argument");
   HIP_TRY(hipSetDevice(s->device));
@@ -1206,11 +1221,10 @@ int saa_debug_time_ablated(saa_solver *s, int32_t variant, int32_t nsteps, doubl
   return check_launch();
 }
 
-// Diagnostic, not part of include/saa_hip.h (tools/peer_loopback.py): attach this rank to `world - 1` imaginary
-// neighbours that hold exactly the same shared nodes and whose inbox segments live in this rank's own inbox, then
-// time saa_step_peer.  Every shared force comes back (world - 1) times: the state is meaningless.
-int saa_debug_peer_loopback(saa_solver *s, int32_t world) {
-  if (!s || world < 2 || world > 8 || s->n_shared <= 0) return fail(SAA_E_ARG, "saa_debug_peer_loopback: bad argument");
+#endif  // SAA_DIAGNOSTICS
+
+int saa_peer_attach_loopback(saa_solver *s, int32_t world) {
+  if (!s || world < 2 || world > 8 || s->n_shared <= 0) return fail(SAA_E_ARG, "saa_peer_attach_loopback: bad argument");
   uint8_t handle[64];
   std::vector<int32_t> order(s->n_shared);
   if (int rc = saa_peer_export(s, world, handle, order.data())) return rc;
@@ -1223,6 +1237,7 @@ int saa_debug_peer_loopback(saa_solver *s, int32_t world) {
   return peer_attach_impl(s, 0, world, nullptr, nullptr, counts.data(), slots.data(), orders.data(), true);
 }
 
+#ifdef SAA_DIAGNOSTICS
 int saa_debug_time_peer(saa_solver *s, int32_t nsteps, double *elapsed_ms) {
   if (!s || !elapsed_ms || nsteps < 0) return fail(SAA_E_ARG, "saa_debug_time_peer: bad argument");
   HIP_TRY(hipSetDevice(s->device));
@@ -1256,5 +1271,6 @@ int saa_debug_read_stamps(saa_solver *s, unsigned long long *out, int64_t n) {
   HIP_TRY(hipMemcpy(out, s->scratch[0].p, n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   return SAA_OK;
 }
+#endif  // SAA_DIAGNOSTICS
 
 }  // extern "C"

@@ -129,8 +129,10 @@ hipError_t configure_kernels(int lds_bytes);
 void launch_fused_step(const DeviceMesh &m, int threads, int lds_bytes, hipStream_t st, const double *d0,
                        const double *dn, double *d1, double *iface, const double *table_row, double *hist_row,
                        const StepConsts &k);
+#ifdef SAA_DIAGNOSTICS
 void launch_fused_step_ablated(int variant, const DeviceMesh &m, int threads, int lds_bytes, hipStream_t st,
                                const double *d0, const double *dn, double *d1, const StepConsts &k, double *dbg);
+#endif
 void launch_force_only(const DeviceMesh &m, int threads, int lds_bytes, hipStream_t st, const double *d,
                        double *f);
 void launch_iface_finish(const DeviceMesh &m, const SharedMap &sh, hipStream_t st, const double *d0,

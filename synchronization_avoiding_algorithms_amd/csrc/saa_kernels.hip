@@ -971,7 +971,8 @@ void launch_peer_selftest(const PeerMap &pm, hipStream_t st, const double *own, 
   hipLaunchKernelGGL(peer_selftest_kernel, dim3(blocks), dim3(256), 0, st, pm, own, out, seq);
 }
 
-// Diagnostic only (tools/ablate.py): the step kernel with one phase removed; results are garbage.
+#ifdef SAA_DIAGNOSTICS
+// Diagnostic build only (tools/ablate.py): the step kernel with one phase removed; results are garbage.
 void launch_fused_step_ablated(int variant, const DeviceMesh &m, int threads, int lds_bytes, hipStream_t st,
                                const double *d0, const double *dn, double *d1, const StepConsts &k, double *dbg) {
   double *none = nullptr;
@@ -989,6 +990,7 @@ void launch_fused_step_ablated(int variant, const DeviceMesh &m, int threads, in
   }
 #undef SAA_ABL
 }
+#endif  // SAA_DIAGNOSTICS
 
 int persistent_lds_bytes(int max_local, int max_owned, int max_items, int max_halo) {
   const int fstride = force_stride_for(max_owned);

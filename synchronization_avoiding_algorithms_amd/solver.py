@@ -241,6 +241,11 @@ class HipExplicitSolver:
                                              counts.ctypes.data_as(p32), slots.ctypes.data_as(p32),
                                              orders.ctypes.data_as(p32)))
 
+    def peer_attach_loopback(self, world: int = 2):
+        """One-GPU rehearsal of the peer exchange (``saa_peer_attach_loopback``): ``world - 1`` imaginary neighbours
+        holding this rank's shared nodes; shared nodes are then updated with ``world`` x their local partial force."""
+        _lib.check(self._lib.saa_peer_attach_loopback(self._h, int(world)))
+
     def peer_selftest(self) -> bool:
         ok = C.c_int32()
         _lib.check(self._lib.saa_peer_selftest(self._h, C.byref(ok)))

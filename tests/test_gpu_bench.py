@@ -1,0 +1,44 @@
+"""bench.py as the driver runs it: plain ``python bench.py --gpus N ...`` (N > 1 starts its own ranks), one JSON line."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(*flags, timeout=900):
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), *flags], capture_output=True, text=True,
+                       timeout=timeout, env=env, cwd=REPO)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_two_ranks_launch_themselves_and_print_one_line():
+    """N = 2 on the one-GPU box: both ranks share cuda:0, gloo process group (what --same-device is for)."""
+    out = _run("--gpus", "2", "--same-device", "--backend", "gloo", "--refine", "4", "--steps", "40", "--warmup", "10")
+    assert out["n_gpus"] == 2 and out["steps"] == 40 and out["warmup"] == 10 and out["timed_calls"] >= 1
+    assert out["metric"] == "element_updates_per_s" and out["value"] > 0 and out["scaling"] == "weak"
+    assert "2 x-slab" in out["config"]["workload"]
+    assert abs(out["value"] - 150 * 4 ** 3 * 1e3 / out["ms_per_step"]) < 1e-6 * out["value"]
+    sa = out["sync_avoiding"]
+    assert sa["value"] > 0 and sa["state_finite"]
+
+
+def test_headline_at_the_drivers_flags_is_warm():
+    """The driver's own command (BENCH_r01.json: --steps 20 --warmup 5).  Round 1 timed a cold first cooperative
+    launch there (33x below the kernel's rate); the timed call must run warm and agree with the kernel-level figure."""
+    out = _run("--gpus", "1", "--steps", "20", "--warmup", "5", "--no-cpu-baseline")
+    roof = out["roofline"]
+    assert roof["launches_timed"] >= 10 and 0.3 < roof["frac"] < 1.5
+    kernel_rate = 1028850 / (roof["us_per_step"] * 1e-6)
+    assert out["value"] > kernel_rate / 1.5, (out["value"], kernel_rate)
+    assert out["timed_calls"] * out["steps"] * out["ms_per_step"] >= 45.0  # the timed region lasted >= ~50 ms

@@ -1,0 +1,148 @@
+"""GPU parity at BASELINE.json's full sizes, through the very plans bench.py runs.
+
+* config 2 - the synthetic ~1M-tet cantilever (n = 19: 1 028 850 tets, 190 400 nodes) on one GPU: 256 blocks x 1024
+  threads, the resident multi-step kernel with its ~128 KB LDS image and multi-round item lists, and the fused
+  one-launch-per-step kernel;
+* configs 3/4 - the per-GPU workload of the 8-GPU run: the middle x-slab (rank 3 of 8) of the ~8M-tet cantilever
+  (n = 38: 1 031 016 tets, 182 520 nodes, 3 042 shared nodes on two interface planes), stepped through the direct peer
+  exchange (push / stamped entries / poll / rank-ordered sums, fused and resident PEER kernels) with the loop-back
+  attach: its one imaginary neighbour returns this rank's own partial force, i.e. shared nodes are updated with
+  exactly 2 x their local K_r d (saa_hip.h: saa_peer_attach_loopback), which the oracle reproduces.
+
+No reference run exists at these sizes (its set-up is dense O(N^2..N^3)): the oracle here is
+``fem_oracle.MatrixFreeStiffness`` - the reference's element matrices applied element by element - pinned to the
+reference's own ``LocalK.dot`` on beam_coarse in tests/test_oracle_golden.py; plus size-independent properties (rigid
+translation and infinitesimal rotation produce no force).
+
+Tolerances (fp64): K.d rel-L2 < 1e-13; 200 steps from a rough state rel-L2 < 1e-11 (both kernels, against the oracle
+and against each other); rigid modes: max|f| < 1e-12 x max|K.d_rand| for displacements of the same size.
+"""
+import numpy as np
+import pytest
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+E, NU, RHO, FZ, ALPHA, GAMMA = 1e6, 0.3, 1.0, 0.5, 0.5, 0.9
+N_STEPS = 200
+
+
+def _build(mesh, n_parts, rank):
+    """The partition exactly as bench.py builds it (same host code, automatic plan)."""
+    import synchronization_avoiding_algorithms_amd as saa
+    from synchronization_avoiding_algorithms_amd import fem_setup as fs
+    from synchronization_avoiding_algorithms_amd.mesh import clamp_nodes, slab_partition
+
+    lmd, mu = fs.lame(E, NU)
+    epart = slab_partition(mesh, n_parts) if n_parts > 1 else np.zeros(len(mesh.tets), dtype=np.int64)
+    layouts, gshared = fs.build_layouts(mesh.tets, epart, n_parts, len(mesh.points), clamp_nodes(mesh))
+    lay = layouts[rank]
+    lumped, fpre = fs.lumped_mass_and_load(mesh.points, mesh.tets, RHO, FZ)
+    dt = fs.cfl_dt(mesh.points, mesh.tets, E, NU, RHO, GAMMA)
+    sol = saa.HipExplicitSolver(mesh.points[lay.nodes], lay.cells_local, lumped[lay.local_dof], fpre[lay.local_dof],
+                                lay.dirichlet_dofs, lmd, mu, dt, ALPHA, shared_local=lay.shared_local,
+                                shared_slots=lay.shared_slots, n_global_shared=len(gshared))
+    return sol, lay, dt, lumped[lay.local_dof], fpre[lay.local_dof], (lmd, mu)
+
+
+def _operator_properties(sol, K, pts, rng):
+    d = rng.uniform(-1e-2, 1e-2, size=(sol.n_dof, 1))
+    f_ref = K.dot(d)
+    assert rel_l2(sol.internal_force(d), f_ref) < 1e-13
+    scale = np.abs(f_ref).max()
+    # rigid translation and infinitesimal rotation u = w x (x - c): zero strain, zero force (displacements <= 1e-2)
+    t = np.tile([1.0e-2, -0.5e-2, 0.25e-2], sol.n_nodes)
+    assert np.abs(sol.internal_force(t)).max() < 1e-12 * scale
+    w = np.array([3e-4, -4e-4, 5e-4])
+    u = np.cross(w, pts - pts.mean(axis=0))
+    assert 1e-3 < np.abs(u).max() < 1.2e-2
+    assert np.abs(sol.internal_force(u.ravel())).max() < 1e-12 * scale
+    assert np.abs(K.dot(u.ravel())).max() < 1e-12 * scale  # the oracle agrees that it is a null vector
+
+
+def _rough_state(n_dof, dirichlet, rng):
+    """Every dof moves from the first step on (a smooth start would leave most of the 200 steps near zero)."""
+    d0 = rng.uniform(-1e-4, 1e-4, size=(n_dof, 1))
+    dn = d0 + rng.uniform(-1e-6, 1e-6, size=(n_dof, 1))
+    d0[dirichlet] = 0
+    dn[dirichlet] = 0
+    return d0, dn
+
+
+def test_config2_one_million_tets_resident_and_fused_kernels():
+    from oracle import fem_oracle as fo
+    from synchronization_avoiding_algorithms_amd.mesh import structured_beam
+
+    mesh = structured_beam(19)
+    assert len(mesh.tets) == 1028850 and len(mesh.points) == 190400
+    sol, lay, dt, l_M, F, (lmd, mu) = _build(mesh, 1, 0)
+    st, info = sol.plan_stats(), sol.resident_kernel_info()
+    # the plan of the headline bench line: one 1024-thread workgroup per CU, resident kernel available
+    assert st["n_blocks"] == 256 and st["threads"] == 1024 and info["capable"] and info["lds_bytes"] <= 160 * 1024
+    K = fo.MatrixFreeStiffness(lay.cells_local, mesh.points[lay.nodes], lmd, mu)
+    rng = np.random.default_rng(19)
+    _operator_properties(sol, K, mesh.points[lay.nodes], rng)
+
+    d0, dn = _rough_state(sol.n_dof, lay.dirichlet_dofs, rng)
+    tn, o0, on = 0.25, d0, dn
+    for _ in range(N_STEPS):
+        o1 = fo.explicit_step(K, F, lay.dirichlet_dofs, tn, dt, o0, on, l_M, ALPHA)
+        on, o0, tn = o0, o1, tn + dt
+    got = {}
+    for name, resident in (("resident", True), ("fused", False)):
+        sol.set_resident_kernel(resident)
+        sol.set_state(d0, dn, 0.25)
+        sol.step(N_STEPS)
+        g0, gn, gt = sol.get_state()
+        assert gt == tn
+        assert rel_l2(g0, o0) < 1e-11 and rel_l2(gn, on) < 1e-11, name
+        got[name] = g0
+    assert rel_l2(got["resident"], got["fused"]) < 1e-11
+    assert np.abs(o0).max() > 1e-6
+    sol.close()
+
+
+def test_config3_middle_slab_of_the_8gpu_partition_through_the_peer_exchange():
+    import torch
+    from oracle import fem_oracle as fo
+    from synchronization_avoiding_algorithms_amd.mesh import structured_beam
+
+    mesh = structured_beam(38)
+    assert len(mesh.tets) == 8230800
+    sol, lay, dt, l_M, F, (lmd, mu) = _build(mesh, 8, 3)
+    pts = mesh.points[lay.nodes]
+    del mesh
+    n_sh = len(lay.shared_local)
+    assert len(lay.cells_local) == 1031016 and n_sh == 3042
+    assert sol.resident_kernel_info()["capable"]
+    K = fo.MatrixFreeStiffness(lay.cells_local, pts, lmd, mu)
+    rng = np.random.default_rng(38)
+    _operator_properties(sol, K, pts, rng)  # the partial K_r of this rank, interface rows included
+
+    sol.peer_attach_loopback(2)
+    sh_dof = lay.loc_dof_shared
+    d0, dn = _rough_state(sol.n_dof, lay.dirichlet_dofs, rng)
+    tn, o0, on = 0.25, d0, dn
+    hist_ref = np.zeros((N_STEPS, 3 * n_sh))
+    for i in range(N_STEPS):
+        f = K.dot(o0)
+        f[sh_dof] = f[sh_dof] + f[sh_dof]  # rank 0's own force + the imaginary rank 1's copy of it, in rank order
+        o1 = fo.cd_update(f, F, l_M, o0, on, dt, tn, ALPHA, lay.dirichlet_dofs)  # Dynamic_solver.py:26-32
+        hist_ref[i] = o1[sh_dof, 0]                                              # Online_predictor.py:260
+        on, o0, tn = o0, o1, tn + dt
+    got = {}
+    for name, resident in (("resident", True), ("fused", False)):
+        sol.set_resident_kernel(resident)
+        sol.set_state(d0, dn, 0.25)
+        hist = torch.zeros((N_STEPS, 3 * n_sh), dtype=torch.float64, device="cuda")
+        sol.step_peer(N_STEPS, hist, 0)
+        g0, gn, gt = sol.get_state()
+        assert gt == tn
+        assert rel_l2(g0, o0) < 1e-11 and rel_l2(gn, on) < 1e-11, name
+        h = hist.cpu().numpy()
+        assert np.array_equal(h[-1], g0[sh_dof, 0])
+        assert rel_l2(h, hist_ref) < 1e-11, name
+        got[name] = g0
+    assert rel_l2(got["resident"], got["fused"]) < 1e-11
+    sol.close()

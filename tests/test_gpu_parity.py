@@ -317,20 +317,15 @@ def test_resident_kernel_equals_one_launch_per_step(n, block_nodes, threads, mon
 
 def test_peer_exchange_inside_the_resident_kernel(monkeypatch):
     """saa_step_peer through the resident kernel against saa_step_peer with one launch per step, on one process:
-    the diagnostic loop-back attach lets every shared node have two imaginary co-holders living in this rank's own
+    the loop-back attach (saa_peer_attach_loopback) lets every shared node have two imaginary co-holders living in this rank's own
     inbox (tools/peer_loopback.py), so pushes, stamps, parity double-buffering and rank-ordered sums all run."""
-    import ctypes as C
-
     import torch
-    from synchronization_avoiding_algorithms_amd import _lib
     from synchronization_avoiding_algorithms_amd.mesh import structured_beam
 
     mesh = structured_beam(6)
     shared = np.unique(np.random.default_rng(5).integers(0, len(mesh.points), size=60)).astype(np.int32)
     kw = dict(block_nodes=150, threads=256, shared_local=shared, shared_slots=np.arange(len(shared), dtype=np.int32),
               n_global_shared=len(shared))
-    lib = _lib.load()
-    lib.saa_debug_peer_loopback.restype = C.c_int
     out = []
     for resident in (False, True):
         if not resident:
@@ -338,7 +333,7 @@ def test_peer_exchange_inside_the_resident_kernel(monkeypatch):
         sol, _, _, _, _ = _serial_solver(mesh, **kw)
         monkeypatch.delenv("SAA_NO_PERSISTENT", raising=False)
         assert sol.resident_kernel_info()["capable"] == resident
-        _lib.check(lib.saa_debug_peer_loopback(sol._h, C.c_int32(3)))
+        sol.peer_attach_loopback(3)
         hist = torch.zeros((300, 3 * len(shared)), dtype=torch.float64, device="cuda")
         for k, row in ((3, 0), (40, 3), (1, 43), (101, 44)):
             sol.step_peer(k, hist, row)

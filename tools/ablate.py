@@ -4,7 +4,10 @@ import ctypes as C
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _diag import use_diag_library  # noqa: E402
+
+use_diag_library()  # diagnostic build of the library; the product .so has none of the saa_debug_* entry points
 import numpy as np  # noqa: E402
 
 from bench import build_rank_solver  # noqa: E402

@@ -2,7 +2,7 @@
 """Diagnostic: cost of the in-kernel peer exchange (push + collect phases of fused_step_kernel<PEER>) on ONE GPU.
 
 Takes the partition a middle rank holds in the driver's N-GPU bench (x-slab of the 25n x n x n beam, two
-interfaces), attaches it to imaginary neighbours living in its own inbox (saa_debug_peer_loopback) and times
+interfaces), attaches it to imaginary neighbours living in its own inbox (saa_peer_attach_loopback) and times
 saa_step_peer against plain saa_step on the same partition.  Local memory latency stands in for xGMI's.
 
     python tools/peer_loopback.py [--gpus 8] [--rank 3] [--steps 2000]
@@ -14,7 +14,10 @@ import sys
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _diag import use_diag_library  # noqa: E402
+
+use_diag_library()  # diagnostic build of the library; the product .so has none of the saa_debug_* entry points
 
 from bench import ALPHA, E, GAMMA, N_FOR_GPUS, NU, RHO, FZ  # noqa: E402
 
@@ -50,8 +53,7 @@ def main():
                                      threads=args.threads)
 
     lib = _lib.load()
-    for name in ("saa_debug_peer_loopback", "saa_debug_time_peer"):
-        getattr(lib, name).restype = C.c_int
+    lib.saa_debug_time_peer.restype = C.c_int
     print(f"rank {args.rank} of {args.gpus}: {len(lay.cells_local)} tets, {len(lay.nodes)} nodes, "
           f"{len(lay.shared_local)} shared nodes", flush=True)
     plain = make()
@@ -61,7 +63,7 @@ def main():
     plain.close()
     for world in (() if args.plain_only else (2, 3)):
         sol = make()
-        _lib.check(lib.saa_debug_peer_loopback(sol._h, C.c_int32(world)))
+        sol.peer_attach_loopback(world)
         ms = C.c_double()
         _lib.check(lib.saa_debug_time_peer(sol._h, C.c_int32(200), C.byref(ms)))
         _lib.check(lib.saa_debug_time_peer(sol._h, C.c_int32(args.steps), C.byref(ms)))

@@ -1,17 +1,16 @@
 #!/usr/bin/env python3
-"""Diagnostic: where a step of the resident kernel spends its cycles (build with -DSAA_PERSIST_STAMPS).
-
-    cd synchronization_avoiding_algorithms_amd/csrc && hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC -shared \
-        -munsafe-fp-atomics -DSAA_PERSIST_STAMPS saa_kernels.hip saa_api.cpp saa_plan.cpp -o ../../tools/exp/libsaa_stamps.so -ldl
-    SAA_LIB_PATH=tools/exp/libsaa_stamps.so python tools/persist_stamps.py
-"""
+"""Diagnostic: where a step of the resident kernel spends its cycles (diagnostic build with -DSAA_PERSIST_STAMPS,
+made on the fly: libsaa_hip_diag.so)."""
 import os
 import sys
 
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _diag import use_diag_library  # noqa: E402
+
+use_diag_library(["-DSAA_PERSIST_STAMPS"])  # diagnostic build of the library; the product .so has none of the saa_debug_* entry points
 from bench import build_rank_solver  # noqa: E402
 from synchronization_avoiding_algorithms_amd.mesh import structured_beam  # noqa: E402
 
