@@ -342,6 +342,31 @@ void setup_persistent(saa_solver *s) {
   s->ps_lds = lds;
   s->ps_max_items = max_items;
   s->ps_steps = 0;
+  // Census: one launch of the very kernel (same registers, same LDS, same grid) in which every workgroup checks in and
+  // waits for all the others - the proof of co-residency that the stamped waits of the step loop rely on.  50 ms bound;
+  // a grid that does not fit keeps the one-launch-per-step kernel.
+  {
+    DevBuf<int32_t> counter;
+    bool ok = counter.upload(std::vector<int32_t>(1, 0)) == hipSuccess;
+    saa::PersistArgs a{};
+    a.census = counter.p;
+    a.err = s->ps_err.p;
+    a.timeout_ticks = 5000000;  // 50 ms of the 100 MHz wall clock
+    a.max_items = max_items;
+    ok = ok && saa::launch_persistent_steps(s->mesh, s->threads, lds, s->stream, s->consts, s->ps_args.p, a, 0) == hipSuccess;
+    ok = ok && hipStreamSynchronize(s->stream) == hipSuccess;
+    int32_t e = 1, seen = 0;
+    ok = ok && hipMemcpy(&e, s->ps_err.p, sizeof(e), hipMemcpyDeviceToHost) == hipSuccess &&
+         hipMemcpy(&seen, counter.p, sizeof(seen), hipMemcpyDeviceToHost) == hipSuccess;
+    counter.release();
+    if (!ok || e != 0 || seen != nb) {
+      (void)hipGetLastError();
+      const int32_t zero = 0;
+      (void)hipMemcpy(s->ps_err.p, &zero, sizeof(zero), hipMemcpyHostToDevice);
+      s->ps_entries.release();
+      return;
+    }
+  }
   s->ps_capable = true;
 }
 
@@ -393,11 +418,8 @@ int try_persistent_steps(saa_solver *s, int32_t nsteps, const double *table_dev,
     a.traj_cols = s->rec_cols;
     a.step_index0 = s->rec_index;
     a.save_every = s->rec_every;
-    // argument block: stream-ordered copy from pageable memory (staged before the call returns; lands after the
-    // previous launch, which may still be reading the block, has finished)
-    HIP_TRY(hipMemcpyAsync(s->ps_args.p, &a, sizeof(a), hipMemcpyHostToDevice, s->stream));
     const hipError_t e = saa::launch_persistent_steps(s->mesh, s->threads, s->ps_lds, s->stream, s->consts,
-                                                      s->ps_args.p, peer ? 2 : (table_dev != nullptr ? 1 : 0));
+                                                      s->ps_args.p, a, peer ? 2 : (table_dev != nullptr ? 1 : 0));
     if (e != hipSuccess) {  // e.g. the device cannot hold all workgroups right now: keep the per-step path
       (void)hipGetLastError();
       s->ps_capable = false;

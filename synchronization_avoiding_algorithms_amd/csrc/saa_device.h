@@ -113,6 +113,7 @@ struct PersistArgs {
   const int32_t *new_to_old;
   int64_t traj_cols, step_index0;  // step index of the first step of this launch
   int32_t save_every;
+  int32_t *census;          // non-null: census launch - every workgroup checks in here and waits for the full count
 };
 
 // Recorder of the per-step paths: one small kernel after a step that is due.
@@ -122,8 +123,9 @@ void launch_record_column(int n_nodes, const int32_t *new_to_old, hipStream_t st
 int persistent_lds_bytes(int max_local, int max_owned, int max_items, int max_halo);
 // How many workgroups of the resident kernel can be co-resident on the device (0 on error).
 int persistent_max_blocks(int device, int threads, int lds_bytes);
+// Writes `a` to the device-side argument block (a one-thread kernel, stream-ordered) and launches the resident kernel.
 hipError_t launch_persistent_steps(const DeviceMesh &m, int threads, int lds_bytes, hipStream_t st, const StepConsts &k,
-                                   const PersistArgs *args_dev, int mode);
+                                   PersistArgs *args_dev, const PersistArgs &a, int mode);
 
 hipError_t configure_kernels(int lds_bytes);
 void launch_fused_step(const DeviceMesh &m, int threads, int lds_bytes, hipStream_t st, const double *d0,

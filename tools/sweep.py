@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Diagnostic: step time of the fused kernel over (block_nodes, threads) on the n-refined beam."""
+"""Diagnostic: step time over (block_nodes, threads) on the n-refined beam: calls of 1000 steps (resident kernel when
+the plan admits it, else the fused kernel)."""
 import os
 import sys
 
@@ -24,6 +25,8 @@ for bn in (int(v) for v in (sys.argv[2].split(",") if len(sys.argv) > 2 else "74
         sol.time_steps(200)
         ms = sol.time_steps(1000)
         st = sol.plan_stats()
+        info = sol.resident_kernel_info()
         print(f"block_nodes {bn:5d} threads {th:5d}: {ms:8.3f} us/step  blocks {st['n_blocks']} owned {st['max_owned']} "
-              f"local {st['max_local']} copies {st['n_elem_copies']} lds {st['lds_bytes']}", flush=True)
+              f"local {st['max_local']} copies {st['n_elem_copies']} lds {st['lds_bytes']} conflict "
+              f"{st['lds_conflict_factor']:.3f} resident {info['capable']} ({info['lds_bytes']} B)", flush=True)
         sol.close()
