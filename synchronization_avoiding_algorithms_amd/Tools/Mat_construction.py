@@ -8,7 +8,7 @@ from __future__ import annotations
 import numpy as np
 from scipy.sparse import csr_matrix
 
-from ..fem_setup import signed_volumes
+from ..fem_setup import element_stiffness, signed_volumes
 from ..solver import HipExplicitSolver
 from .Distributed_tools import local_mat_node
 
@@ -85,3 +85,41 @@ def Global_Assembly_no_bc(deg, Cells, Points, elas, t):
     nodal = np.bincount(Cells.ravel(), weights=np.repeat(vol / 4.0, 4), minlength=n)
     F = np.outer(nodal, f).reshape(-1, 1)
     return M, None, F
+
+
+#: (3N) beyond which ``Global_Assembly`` hands back scipy-CSR matrices instead of dense arrays
+DENSE_DOF_LIMIT = 12000
+
+
+def Global_Assembly(deg, Cells, Points, Dirichlet, elas, t, Facets=None, Neumann=None, steady=False, sparse=None):
+    """``Mat_construction.py:155-196``: consistent mass, stiffness and load with the rows and columns of the Dirichlet
+    dofs left out (the caller then puts 1 on their diagonal: ``Data_prepare.py:185-190``, ``Steady_solvers.py:16-21``).
+    Same call, same return triple ``(M, K, F)`` with ``F (3N,1)``.
+
+    Assembled from closed-form element matrices in O(N) instead of the reference's Python quadruple loop over dense
+    ``(3N)^2`` arrays.  ``M`` and ``K`` are dense ``ndarray`` (what ``np.linalg.solve`` in the reference's drivers needs)
+    while ``3N <= DENSE_DOF_LIMIT``, scipy CSR beyond it (a dense 1M-tet matrix would hold 2.6 TB); ``sparse=True/False``
+    forces either.  ``steady`` only changes how prescribed NON-zero Dirichlet values would enter ``F`` in the reference,
+    and those are all zero there (``:187-190``), so it has no effect here either."""
+    if deg != 1:
+        raise NotImplementedError("linear tetrahedra only (Data_prepare.py:43-44)")
+    Points = np.asarray(Points, dtype=np.float64)
+    Cells = np.asarray(Cells, dtype=np.int64)[:, :4]
+    n3 = 3 * len(Points)
+    free = np.ones(n3, dtype=bool)
+    free[np.asarray(list(Dirichlet), dtype=np.int64)] = False
+    vol = signed_volumes(Points, Cells)
+    dof = (3 * Cells[:, :, None] + np.arange(3)[None, None, :]).reshape(-1, 12)
+    rows, cols = np.repeat(dof, 12, axis=1).ravel(), np.tile(dof, (1, 12)).ravel()
+    keep = free[rows] & free[cols]
+    Ke = element_stiffness(Points, Cells, elas.lmd, elas.mu)
+    # consistent mass rho*V/20*(1 + delta_ab) on each axis (the 4-point rule integrates N_a N_b exactly)
+    Me = np.kron((np.ones((4, 4)) + np.eye(4)) / 20.0, np.eye(3))[None] * (elas.rho * vol)[:, None, None]
+    K = csr_matrix((Ke.ravel()[keep], (rows[keep], cols[keep])), shape=(n3, n3))
+    M = csr_matrix((Me.ravel()[keep], (rows[keep], cols[keep])), shape=(n3, n3))
+    nodal = np.bincount(Cells.ravel(), weights=np.repeat(vol / 4.0, 4), minlength=len(Points))
+    F = np.outer(nodal, np.asarray(elas.f(None, t), dtype=np.float64).ravel()).reshape(-1, 1)
+    F[~free] = 0.0
+    if sparse is None:
+        sparse = n3 > DENSE_DOF_LIMIT
+    return (M, K, F) if sparse else (M.toarray(), K.toarray(), F)

@@ -31,6 +31,31 @@ def signed_volumes(points: np.ndarray, cells: np.ndarray) -> np.ndarray:
     return np.einsum("ij,ij->i", e1, np.cross(e2, e3)) / 6.0
 
 
+def element_stiffness(points, cells, lmd, mu) -> np.ndarray:
+    """``(ne,12,12)`` element stiffness of linear tets in closed form, ``K_e = (detJ/6) B^T D B`` with
+    ``grad N_a = c_a/detJ`` (``c_a`` = cofactor rows of the edge matrix) - the matrix the 4-point quadrature of
+    ``Local_K_coronary`` (``Mat_construction.py:79-119``) sums to; dof order ``3a + A``, Voigt rows xx,yy,zz,yz,xz,xy
+    (``:99-104``).  Host-side set-up only (``Global_Assembly``); the step kernels never form it."""
+    p = np.asarray(points, dtype=np.float64)[np.asarray(cells)]
+    e1, e2, e3 = p[:, 1] - p[:, 0], p[:, 2] - p[:, 0], p[:, 3] - p[:, 0]
+    c = np.stack([np.cross(e2, e3), np.cross(e3, e1), np.cross(e1, e2)], axis=1)          # (ne,3,3) = detJ * grad N_1..3
+    det = np.einsum("ij,ij->i", e1, c[:, 0])
+    grad = np.concatenate([-c.sum(axis=1, keepdims=True), c], axis=1) / det[:, None, None]  # (ne,4,3)
+    ne = len(grad)
+    B = np.zeros((ne, 6, 12))
+    gx, gy, gz = grad[..., 0], grad[..., 1], grad[..., 2]
+    ix, iy, iz = np.arange(0, 12, 3), np.arange(1, 12, 3), np.arange(2, 12, 3)
+    B[:, 0, ix], B[:, 1, iy], B[:, 2, iz] = gx, gy, gz
+    B[:, 3, iy], B[:, 3, iz] = gz, gy
+    B[:, 4, ix], B[:, 4, iz] = gz, gx
+    B[:, 5, ix], B[:, 5, iy] = gy, gx
+    D = np.zeros((6, 6))
+    D[:3, :3] = lmd
+    D[np.arange(3), np.arange(3)] += 2.0 * mu
+    D[np.arange(3, 6), np.arange(3, 6)] = mu
+    return np.matmul(np.matmul(B.transpose(0, 2, 1), D), B) * (det / 6.0)[:, None, None]
+
+
 def lumped_mass_and_load(points, cells, rho, fz):
     """(lumped_M, F_pre), each ``(3N,1)`` like the arrays broadcast at ``Data_prepare.py:194-197``."""
     n = len(points)

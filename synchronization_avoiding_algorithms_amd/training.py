@@ -97,9 +97,28 @@ class GraphedTrainStep:
         self.graph.replay()  # capture does not execute: this is the step for the batch just copied in
 
 
-def model_train(device, model, batches, criterion, optimizer, n_future, graphed=None):
-    """One epoch of recursive-decoding training (``DNN_tools.py:103-165``, 'recursive' method).
+def _decode_teacher_forced(model, X, Y, n_future, ratio):
+    """'mtf' decoding of ``DNN_tools.py:131-142`` (not used in the paper): with probability ``ratio`` the next decoder
+    input is the truth instead of the model's own output."""
+    import random
+
+    h, c = model.encoder(X)
+    inp, outs = X[:, -1, :], []
+    for i in range(n_future):
+        out, h, c = model.decoder(inp, h, c)
+        outs.append(out)
+        inp = Y[:, i, :] if random.random() < ratio else out
+    return torch.stack(outs, dim=1)
+
+
+def model_train(device, model, batches, criterion, optimizer, n_future, training_method="recursive", ratio=0.5,
+                graphed=None):
+    """One epoch of training with the signature of ``DNN_tools.py:103`` (``batches``: any iterable of ``(X, Y)``
+    mini-batches, e.g. a ``DataLoader`` over ``MyDataset``).  'recursive' decoding (the paper's method) may run as a
+    replayed HIP graph (``graphed``); 'mtf' runs eagerly.
     Returns (sum of batch losses, sum of R2 accuracies, sum of relative accuracies, model)."""
+    if training_method not in ("recursive", "mtf"):
+        raise ValueError("training_method must be 'recursive' or 'mtf'")
     model.train()
     # the three running sums stay on the device (float64, like the reference's Python floats) and come back once per
     # epoch: a .item() per batch would stall the launch-bound GPU three times per optimiser step
@@ -107,11 +126,15 @@ def model_train(device, model, batches, criterion, optimizer, n_future, graphed=
     if graphed is not None:
         graphed.sums.zero_()
     for X, Y in batches:
-        if graphed is not None and X.shape == graphed.X.shape:
+        if graphed is not None and training_method == "recursive" and X.shape == graphed.X.shape:
             graphed.run(X, Y)
             continue
         optimizer.zero_grad()
-        out = _decode(model, X, n_future)
+        if training_method == "recursive":
+            out = _decode(model, X, n_future)
+        else:
+            out = _decode_teacher_forced(model, X, Y, n_future, ratio)
+            ratio = ratio - 0.005 if ratio > 0.005 else ratio  # DNN_tools.py:160-163
         loss = criterion(out, Y)
         with torch.no_grad():
             sums[1] += (1.0 - loss / criterion(Y, torch.mean(Y) + torch.zeros_like(Y))).double()
@@ -185,7 +208,7 @@ def train_rank_model(out_dir=".", rank=0, device=None, batch_size=10, learning_r
     for epoch in range(num_epochs):
         tb = _batches(Xtr, Ytr, batch_size, True, gen)
         vb = _batches(Xte, Yte, batch_size, False)
-        lt, r2, _, model = model_train(device, model, tb, criterion, optimizer, n_future, graphed)
+        lt, r2, _, model = model_train(device, model, tb, criterion, optimizer, n_future, graphed=graphed)
         lv, _, _ = model_test(device, model, vb, criterion, n_future) if vb else (float("nan"), 0, 0)
         train_loss.append(lt / len(tb))
         test_loss.append(lv / max(len(vb), 1))

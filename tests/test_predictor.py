@@ -10,19 +10,24 @@ def _weights(g, prefix):
     return {k[len(prefix):]: torch.from_numpy(v) for k, v in g.items() if k.startswith(prefix)}
 
 
-def test_reference_state_dict_loads_and_table_matches(tmp_path):
+def _table_against_reference(tmp_path, device, tol):
     g = load_golden("predictor_table.npz")
     n_in, hid = int(g["input_size"]), int(g["hidden_size"])
     path = tmp_path / "model.pth"
     torch.save(_weights(g, "w::"), path)  # same format as Model_training.py:179-180
-    model = pr.call_model("cpu", int(g["n_s"]), n_in, hid, str(path))
+    model = pr.call_model(device, int(g["n_s"]), n_in, hid, str(path))
     smax, smin = (float(v) for v in g["scale"])
-    NF = pr.encoder_decoder_predictor("cpu", int(g["n"]), model, int(g["n_p"]), int(g["n_f"]), int(g["n_s"]),
+    NF = pr.encoder_decoder_predictor(device, int(g["n"]), model, int(g["n_p"]), int(g["n_f"]), int(g["n_s"]),
                                       n_in, g["d_sol"], smax, smin)
     assert NF.dtype == np.float64 and NF.shape == g["NF"].shape
     # fp32 model: batched vs the reference's batch-1 passes differ by fp32 round-off only
-    assert np.abs(NF - g["NF"]).max() <= 2e-5 * np.abs(g["NF"]).max()
+    assert np.abs(NF - g["NF"]).max() <= tol * np.abs(g["NF"]).max()
     assert np.array_equal(NF, NF.astype(np.float32).astype(np.float64))  # fp32 values widened (:54)
+    return g, model, (smax, smin)
+
+
+def test_reference_state_dict_loads_and_table_matches(tmp_path):
+    _table_against_reference(tmp_path, "cpu", 2e-5)
 
 
 def test_scaling_constants_match_reference():
@@ -68,3 +73,16 @@ def test_device_predictor_graph_replay_equals_eager_calls():
         for n in (50, 90, 120, 200):
             assert torch.allclose(p(n, other), pr.predict_table(model, n, n_p, n_f, n_s, other, 2e-3, -2e-3),
                                   rtol=1e-6, atol=1e-12)
+
+
+@pytest.mark.gpu
+def test_reference_shaped_table_on_the_gpu(tmp_path):
+    """The fixture at the reference's real shape (24 inputs, H = 50, n_p = n_f = 20) through MIOpen / rocBLAS on the
+    GPU, eager and as the replayed HIP graph of DevicePredictor (fp32: 1e-4 of the table's range)."""
+    g, model, (smax, smin) = _table_against_reference(tmp_path, "cuda", 1e-4)
+    dev = pr.DevicePredictor(model, int(g["n_p"]), int(g["n_f"]), int(g["n_s"]), smax, smin)
+    hist = torch.from_numpy(g["d_sol"]).to("cuda")
+    for _ in range(4):  # eager calls, capture, replay
+        table = dev(int(g["n"]), hist)
+    torch.cuda.synchronize()
+    assert np.abs(table.cpu().numpy() - g["NF"]).max() <= 1e-4 * np.abs(g["NF"]).max()

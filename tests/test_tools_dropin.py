@@ -54,3 +54,59 @@ def test_lumped_mass_and_preassembled_load(beam_coarse):
     # the assembled block contains this element's contribution: check symmetry + positive row sums instead
     assert np.allclose(Md, Md.T) and (Md.sum(axis=1) > 0).all()
     assert np.isclose(Md.sum() / 3, 25.0)
+
+
+def test_global_assembly_matches_the_reference(beam_coarse):
+    """``Global_Assembly`` (Mat_construction.py:155-196) as the drivers call it: Data_prepare.py:183 (ramped load at
+    t = 0 and later on the ramp) and Steady_solvers.py:14 (un-ramped, steady=True); dense for the reference's mesh so
+    that the drivers' ``np.linalg.solve(M, F - K@d0)`` keeps working, CSR on request."""
+    from scipy.sparse import csr_matrix, issparse
+
+    g = load_golden("global_assembly.npz")
+    lmd, mu = fo.lame(1e6, 0.3)
+    dirichlet = g["dirichlet_dofs"].tolist()
+    for name, (ramped, t, steady) in {"dyn": (True, 0, False), "dyn_t04": (True, 0.4, False),
+                                      "steady": (False, None, True)}.items():
+        M, K, F = MC.Global_Assembly(1, beam_coarse.tets, beam_coarse.points, dirichlet,
+                                     CM.elasticity(lmd, mu, 1, 0.5, ramped), t, steady=steady)
+        assert isinstance(M, np.ndarray) and isinstance(K, np.ndarray) and F.shape == (330, 1)
+        for tag, A in (("M", M), ("K", K)):
+            ref = csr_matrix((g[f"{name}_{tag}_data"], g[f"{name}_{tag}_indices"], g[f"{name}_{tag}_indptr"]),
+                             shape=A.shape).toarray()
+            assert np.abs(A - ref).max() <= 2e-15 * np.abs(ref).max()
+            assert not A[dirichlet].any() and not A[:, dirichlet].any()
+        assert np.abs(F - g[f"{name}_F"]).max() <= 1e-15
+    Ms, Ks, Fs = MC.Global_Assembly(1, beam_coarse.tets, beam_coarse.points, dirichlet,
+                                    CM.elasticity(lmd, mu, 1, 0.5, False), None, steady=True, sparse=True)
+    assert issparse(Ms) and issparse(Ks) and np.array_equal(Ks.toarray(), K) and np.array_equal(Fs, F)
+    # the ghost-step solve of Data_prepare.py:183-191 written against the drop-in: zero load at t = 0 -> a0 = 0
+    M, K, F = MC.Global_Assembly(1, beam_coarse.tets, beam_coarse.points, dirichlet, CM.elasticity(lmd, mu, 1, 0.5, True), t=0)
+    for dof in dirichlet:
+        M[dof, dof] = 1
+        F[dof] = 0
+    a0 = np.linalg.solve(M, F - K @ np.zeros((330, 1)))
+    assert not a0.any()
+
+
+def test_shape_functions_and_quadrature_match_the_reference():
+    from synchronization_avoiding_algorithms_amd.Tools import Qudrature as Q
+    from synchronization_avoiding_algorithms_amd.Tools import Shape_function_Deriv as S
+
+    g = load_golden("shape_quadrature.npz")
+    for n in (2, 3):
+        nodes, weights = Q.Gauss_Legendre(n)
+        assert np.array_equal(nodes, g[f"q{n}_nodes"]) and np.array_equal(weights, g[f"q{n}_weights"])
+    assert abs(Q.Gauss_Legendre(2)[1].sum() - 1.0 / 6) < 1e-17
+    assert np.array_equal(np.array([S.Shape_Function(1, x) for x in g["xi"]]), g["N"])
+    assert np.array_equal(np.array([S.Shape_Deri(1, x) for x in g["xi"]]), g["dN"])
+    for e, P in enumerate(g["P"]):
+        for q, x in enumerate(g["xi"]):
+            assert np.abs(S.Jacobian(1, P, x) - g["J"][e, q]).max() < 1e-15
+            assert S.IsoparametricMap(1, P, x).shape == (3, 1)
+            assert np.abs(S.IsoparametricMap(1, P, x) - g["X"][e, q]).max() < 4e-15
+    import pytest
+
+    with pytest.raises(NotImplementedError):
+        S.Shape_Function(2, [0.1, 0.1, 0.1])
+    with pytest.raises(NotImplementedError):
+        Q.Gauss_Legendre(4)
