@@ -175,3 +175,22 @@ def _check_three_ranks(tmp_path, use_gpu, exchange="auto", force_resident=False)
 def test_three_ranks_with_triple_owned_nodes_equal_serial(tmp_path):
     """Partition invariance through the compact interface buffer when a node has more than two owners."""
     _check_three_ranks(tmp_path, use_gpu=False)
+
+
+def test_multi_process_cpu_baseline_equals_the_oracle_step():
+    """bench.py's P-core CPU baseline (oracle/cpu_baseline_mp.py: one process per slab, shared-node forces summed in
+    rank order through shared memory) against the oracle's all-ranks-in-one-process restatement of syn_cpus."""
+    from oracle import cpu_baseline_mp
+    from oracle import fem_oracle as fo
+    from synchronization_avoiding_algorithms_amd.mesh import slab_partition, structured_beam
+
+    out = cpu_baseline_mp.run(3, 3, 40, want_state=True, timeout=300)
+    mesh = structured_beam(3)
+    ranks, dt, _, gshared = fo.setup_problem(mesh.points, mesh.tets, mesh.triangles, 3, slab_partition(mesh, 3))
+    d0s, _, _, _ = fo.run_ground_truth(ranks, dt, 40)
+    assert out["n_tets"] == len(mesh.tets) and out["n_shared"] == len(gshared) and out["seconds"] > 0
+    for r in range(3):
+        assert np.abs(d0s[r]).max() > 0
+        # same per-step operations in the same order; the lumped mass comes from the closed form instead of the
+        # oracle's element loop (1e-16 apart), hence not bit-identical
+        assert np.linalg.norm(out["states"][r] - d0s[r]) < 1e-13 * np.linalg.norm(d0s[r])
