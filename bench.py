@@ -37,21 +37,20 @@ N_FOR_GPUS = {1: 19, 2: 24, 3: 27, 4: 30, 5: 32, 6: 34, 7: 36, 8: 38}
 
 
 def build_rank_solver(mesh, n_parts, rank, device, block_nodes=0, threads=0):
+    """One rank's solver outside a process group (tools, the parity leg): layout of that rank only, set-up fields from
+    the HIP kernels; dt from this rank's elements and their neighbours (on the uniform synthetic beams that is the global
+    CFL step; inside a process group PartitionedSolver takes the minimum over the ranks)."""
     import synchronization_avoiding_algorithms_amd as saa
     from synchronization_avoiding_algorithms_amd import fem_setup as fs
     from synchronization_avoiding_algorithms_amd.mesh import clamp_nodes, slab_partition
 
     lmd, mu = fs.lame(E, NU)
     epart = slab_partition(mesh, n_parts) if n_parts > 1 else np.zeros(len(mesh.tets), dtype=np.int64)
-    layouts, gshared = fs.build_layouts(mesh.tets, epart, n_parts, len(mesh.points), clamp_nodes(mesh))
-    lay = layouts[rank]
-    lumped, fpre = fs.lumped_mass_and_load(mesh.points, mesh.tets, RHO, FZ)
-    dt = fs.cfl_dt(mesh.points, mesh.tets, E, NU, RHO, GAMMA)  # == min over ranks of the local CFL steps
-    sol = saa.HipExplicitSolver(mesh.points[lay.nodes], lay.cells_local, lumped[lay.local_dof],
-                                fpre[lay.local_dof], lay.dirichlet_dofs, lmd, mu, dt, ALPHA,
-                                shared_local=lay.shared_local, shared_slots=lay.shared_slots,
-                                n_global_shared=len(gshared), device=device, block_nodes=block_nodes,
-                                threads=threads)
+    lay, gshared, l_M, F_rankwise, dt = fs.rank_problem(mesh.points, mesh.tets, clamp_nodes(mesh), epart, rank, n_parts,
+                                                         E, NU, RHO, FZ, GAMMA, device)
+    sol = saa.HipExplicitSolver(mesh.points[lay.nodes], lay.cells_local, l_M, F_rankwise, lay.dirichlet_dofs, lmd, mu,
+                                dt, ALPHA, shared_local=lay.shared_local, shared_slots=lay.shared_slots,
+                                n_global_shared=len(gshared), device=device, block_nodes=block_nodes, threads=threads)
     return sol, lay, gshared, dt
 
 

@@ -80,8 +80,34 @@ typedef struct saa_plan_stats {
 } saa_plan_stats;
 
 const char *saa_last_error(void);
-/* Library / ABI version; bumps when this header changes (2: peer exchange and resident-kernel entry points; 3: loop-back attach). */
+/* Library / ABI version; bumps when this header changes (2: peer exchange and resident-kernel entry points; 3: loop-back attach; 4: partitioner and set-up kernels). */
 int32_t saa_abi_version(void);
+
+/* Element partition, one part per rank / GPU: the role of `_, epart = part_mesh_kway(size, eptr, eind)` (mgmetis /
+ * ParMETIS, Data_prepare.py:82-101).  Graph partitioning of the dual graph (elements adjacent across a face): recursive
+ * bisection by greedy graph growing + Fiduccia-Mattheyses refinement; deterministic, host only, no HIP call - every rank
+ * computes the same vector from the replicated mesh (Data_prepare.py:76-79) instead of running a distributed partitioner.
+ * tets: (n_elems,4) node ids in [0, n_nodes); epart_out: (n_elems) part of every element; stats_out may be NULL. */
+typedef struct saa_partition_stats {
+  int64_t face_cut;          /* faces between elements of different parts */
+  int64_t min_part, max_part; /* elements in the smallest / largest part */
+  int32_t interface_nodes;   /* nodes touched by more than one part = len(Global_shared), Data_prepare.py:121-124 */
+} saa_partition_stats;
+int saa_part_mesh_kway(int32_t n_parts, int32_t n_elems, int32_t n_nodes, const int32_t *tets, int32_t *epart_out,
+                       saa_partition_stats *stats_out);
+
+/* Set-up fields on the GPU, O(N), for the elements given (a rank passes the elements touching its own nodes):
+ *   lumped_mass_out (3*n_nodes): row sums of the consistent mass = sum_e rho*V_e/4 per node, on its three dofs
+ *                                (Global_Assembly_no_bc + lumping_to_vec: Mat_construction.py:199-231, commons.py:103-107,
+ *                                Data_prepare.py:175-176);
+ *   f_pre_out       (3*n_nodes): pre-assembled un-ramped body force sum_e (V_e/4)*(0,-fz,-fz) (same call, F_pre);
+ *   min_edge_out    (scalar)   : shortest element edge; Meshsize = 2*min_edge/sqrt(24) (commons.py:79-90), from which
+ *                                dt = gamma*Meshsize/sqrt(E/rho/(1-nu^2)) (Data_prepare.py:147).
+ * Replaces the reference's dense (3N)^2 assembly on rank 0.  Signed volumes (detJ/6, Mat_construction.py:93); no
+ * floating-point atomics: nodal sums run in ascending element order (deterministic).  Host pointers in and out, any
+ * output may be NULL. */
+int saa_setup_fields(int32_t device, int32_t n_nodes, int32_t n_elems, const double *xyz, const int32_t *tets, double rho,
+                     double fz, double *lumped_mass_out, double *f_pre_out, double *min_edge_out);
 
 /* Build the device-resident solver for one partition.  Replaces, for this path,
  * Local_assembly_for_stiffness (Mat_construction.py:122-150: no matrix is ever assembled) plus the

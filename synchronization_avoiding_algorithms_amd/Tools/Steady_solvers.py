@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import numpy as np
 
-from ..fem_setup import lumped_mass_and_load
+from ..fem_setup import device_setup_fields
 from ..solver import HipExplicitSolver
 from ..steady import steady_solve, stiffness_diagonal
 
@@ -26,7 +26,7 @@ def Steady_Elasticity_solver(p, Cells, Points, Dirichlet, elas, t=None, Facets=N
     scale = 1.0
     if getattr(elas, "R", False) and t is not None:  # ramped load evaluated at time t (commons.py:35-41)
         scale = t if t <= 1 else 1.0
-    lumped, load = lumped_mass_and_load(Points, Cells, elas.rho, elas.fz * scale)
+    lumped, load, _ = device_setup_fields(Points, Cells, elas.rho, elas.fz * scale, device)
     dirichlet = np.asarray(sorted(Dirichlet), dtype=np.int32)
     sol = HipExplicitSolver(Points, Cells, lumped, load, dirichlet, elas.lmd, elas.mu, 1.0, 0.0, device=device)
     try:

@@ -17,10 +17,10 @@ LIB_PATH = os.environ.get("SAA_LIB_PATH") or os.path.join(_HERE, "libsaa_hip.so"
 #: only; built on request (``build_library(diag=True)``), loaded through SAA_LIB_PATH, never by the package itself
 DIAG_LIB_PATH = os.path.join(_HERE, "libsaa_hip_diag.so")
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "saa_hip.h")
-SOURCES = ["saa_plan.cpp", "saa_kernels.hip", "saa_api.cpp"]
+SOURCES = ["saa_plan.cpp", "saa_partition.cpp", "saa_kernels.hip", "saa_setup.hip", "saa_api.cpp"]
 HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics", "-ldl"]
 
-ABI_VERSION = 3  # what saa_abi_version() of a matching library returns (include/saa_hip.h)
+ABI_VERSION = 4  # what saa_abi_version() of a matching library returns (include/saa_hip.h)
 SAA_OK, SAA_E_ARG, SAA_E_HIP, SAA_E_STATE, SAA_E_CAPACITY = 0, -1, -2, -3, -4
 
 
@@ -43,6 +43,13 @@ class Problem(C.Structure):
     ]
 
 
+class PartitionStats(C.Structure):
+    _fields_ = [("face_cut", C.c_int64), ("min_part", C.c_int64), ("max_part", C.c_int64), ("interface_nodes", C.c_int32)]
+
+    def as_dict(self):
+        return {name: int(getattr(self, name)) for name, _ in self._fields_}
+
+
 class PlanStats(C.Structure):
     _fields_ = [
         ("n_blocks", C.c_int32), ("max_owned", C.c_int32), ("max_local", C.c_int32),
@@ -63,6 +70,8 @@ _H = C.c_void_p
 SIGNATURES = {
     "saa_last_error": (C.c_char_p, []),
     "saa_abi_version": (C.c_int32, []),
+    "saa_part_mesh_kway": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _ip, _ip, C.POINTER(PartitionStats)]),
+    "saa_setup_fields": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _dp, _ip, C.c_double, C.c_double, _dp, _dp, _dp]),
     "saa_create": (C.c_int, [C.POINTER(Problem), C.POINTER(_H)]),
     "saa_destroy": (C.c_int, [_H]),
     "saa_plan_stats_get": (C.c_int, [_H, C.POINTER(PlanStats)]),
@@ -119,7 +128,7 @@ def build_library(force: bool = False, verbose: bool = False, diag: bool = False
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: libsaa_hip.so cannot be built")
     flags = [*HIPCC_FLAGS, *(["-DSAA_DIAGNOSTICS"] if diag else []), *extra_flags]
-    cmd = [hipcc, *flags, *SOURCES[:2], "-x", "hip", SOURCES[2], "-o", out + ".tmp"]
+    cmd = [hipcc, *flags, *SOURCES[:-1], "-x", "hip", SOURCES[-1], "-o", out + ".tmp"]
     res = subprocess.run(cmd, cwd=_CSRC, capture_output=True, text=True)
     if res.returncode != 0:
         raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + res.stderr)

@@ -15,7 +15,9 @@
 
 #include "../../include/saa_hip.h"
 #include "saa_device.h"
+#include "saa_partition.h"
 #include "saa_plan.h"
+#include "saa_setup.h"
 
 namespace {
 
@@ -447,7 +449,7 @@ extern "C" {
 
 const char *saa_last_error(void) { return g_last_error.c_str(); }
 
-int32_t saa_abi_version(void) { return 3; }  // 2: peer exchange and resident kernel; 3: saa_peer_attach_loopback
+int32_t saa_abi_version(void) { return 4; }  // 3: saa_peer_attach_loopback; 4: saa_part_mesh_kway, saa_setup_fields
 
 int saa_plan_host_stats(int32_t n_nodes, int32_t n_elems, const double *xyz, const int32_t *tets,
                         int32_t block_nodes, saa_plan_stats *out) {
@@ -456,6 +458,37 @@ int saa_plan_host_stats(int32_t n_nodes, int32_t n_elems, const double *xyz, con
   std::string err;
   if (!build_fitting_plan(n_nodes, n_elems, xyz, tets, block_nodes, plan, err)) return fail(SAA_E_ARG, err);
   fill_stats(plan, lds_bytes_of(plan), pick_threads(plan, 0), out);
+  return SAA_OK;
+}
+
+int saa_part_mesh_kway(int32_t n_parts, int32_t n_elems, int32_t n_nodes, const int32_t *tets, int32_t *epart_out,
+                       saa_partition_stats *stats_out) {
+  if (!epart_out && n_elems > 0) return fail(SAA_E_ARG, "saa_part_mesh_kway: null output");
+  std::vector<int32_t> epart;
+  saa::PartitionStats st;
+  std::string err;
+  if (!saa::partition_kway(n_parts, n_elems, n_nodes, tets, epart, st, err)) return fail(SAA_E_ARG, err);
+  if (n_elems > 0) std::memcpy(epart_out, epart.data(), epart.size() * sizeof(int32_t));
+  if (stats_out) {
+    stats_out->face_cut = st.face_cut;
+    stats_out->min_part = st.min_part;
+    stats_out->max_part = st.max_part;
+    stats_out->interface_nodes = st.interface_nodes;
+  }
+  return SAA_OK;
+}
+
+int saa_setup_fields(int32_t device, int32_t n_nodes, int32_t n_elems, const double *xyz, const int32_t *tets, double rho,
+                     double fz, double *lumped_mass_out, double *f_pre_out, double *min_edge_out) {
+  if (n_nodes <= 0 || n_elems < 0 || !xyz || (n_elems > 0 && !tets)) return fail(SAA_E_ARG, "saa_setup_fields: bad argument");
+  for (int64_t i = 0; i < 4 * static_cast<int64_t>(n_elems); ++i)
+    if (tets[i] < 0 || tets[i] >= n_nodes) return fail(SAA_E_ARG, "saa_setup_fields: node id out of range");
+  HIP_TRY(hipSetDevice(device));
+  const hipError_t e = saa::setup_fields(n_nodes, n_elems, xyz, tets, rho, fz, lumped_mass_out, f_pre_out, min_edge_out);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(SAA_E_HIP, std::string("saa_setup_fields: ") + hipGetErrorString(e));
+  }
   return SAA_OK;
 }
 

@@ -38,7 +38,7 @@ class PartitionedSolver:
     def __init__(self, points, cells, facets_or_dirichlet_nodes, epart, rank, world,
                  E=1e6, nu=0.3, rho=1.0, fz=0.5, alpha=0.5, gamma=0.9, device=0, process_group=None,
                  tensor_device=None, solver_factory: Optional[Callable] = None, block_nodes=0, threads=0,
-                 native_exchange=True, exchange="auto"):
+                 native_exchange=True, exchange="auto", setup_fields: Optional[Callable] = None):
         import torch
 
         self.rank, self.world = int(rank), int(world)
@@ -51,15 +51,23 @@ class PartitionedSolver:
 
             dn = clamp_nodes(Mesh(points, {"tetra": cells, "triangle": dn}))
         self.lmd, self.mu = fs.lame(E, nu)
-        self.layouts, self.global_shared = fs.build_layouts(cells, epart, world, len(points), dn)
-        self.layout = lay = self.layouts[rank]
-        lumped, fpre = fs.lumped_mass_and_load(points, cells, rho, fz)
-        # min over ranks of the local CFL steps == CFL step of the whole mesh (Data_prepare.py:147-154)
-        self.dt = fs.cfl_dt(points, cells, E, nu, rho, gamma)
+        # this rank's layout only; lumped mass / load / shortest edge from the HIP set-up kernels on the elements that
+        # touch this rank's nodes (``setup_fields`` is injectable for the CPU-only tests of this orchestration)
+        self.layout, self.global_shared, l_M, F_rankwise, dt_local = fs.rank_problem(
+            points, cells, dn, epart, rank, world, E, nu, rho, fz, gamma, device, setup_fields)
+        lay = self.layout
+        # dt = min over the ranks of the local CFL steps (Data_prepare.py:147-154)
+        self.dt = dt_local
+        if self.world > 1:
+            import torch.distributed as dist
+
+            box = [None] * self.world
+            dist.all_gather_object(box, float(dt_local), group=process_group)
+            self.dt = min(box)
         self.alpha = alpha
         factory = solver_factory or _hip_factory
-        self.solver = factory(points=points[lay.nodes], cells=lay.cells_local, l_M=lumped[lay.local_dof],
-                              F_rankwise=fpre[lay.local_dof], dirichlet_dofs=lay.dirichlet_dofs,
+        self.solver = factory(points=points[lay.nodes], cells=lay.cells_local, l_M=l_M,
+                              F_rankwise=F_rankwise, dirichlet_dofs=lay.dirichlet_dofs,
                               lmd=self.lmd, mu=self.mu, dt=self.dt, alpha=alpha,
                               shared_local=lay.shared_local, shared_slots=lay.shared_slots,
                               n_global_shared=len(self.global_shared), device=device,

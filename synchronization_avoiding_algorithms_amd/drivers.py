@@ -138,10 +138,10 @@ def steady_state(mesh, out_dir=".", device=0, tol=1e-12, verbose=False, E=None, 
     rho = DEFAULTS["rho"] if rho is None else rho
     fz = DEFAULTS["fz"] if fz is None else fz
     lmd, mu = fs.lame(E, nu)
-    lumped, fpre = fs.lumped_mass_and_load(mesh.points, mesh.tets, rho, fz)
+    lumped, fpre, min_edge = fs.device_setup_fields(mesh.points, mesh.tets, rho, fz, device)
     dirichlet = fs.node_to_dof(clamp_nodes(mesh))
     sol = HipExplicitSolver(mesh.points, mesh.tets, lumped, fpre, dirichlet, lmd, mu,
-                            fs.cfl_dt(mesh.points, mesh.tets, E, nu, rho, DEFAULTS["gamma"]), DEFAULTS["alpha"],
+                            fs.dt_from_min_edge(min_edge, E, nu, rho, DEFAULTS["gamma"]), DEFAULTS["alpha"],
                             device=device)
     d, iters, rel = steady_solve(sol, fpre, dirichlet, diag=stiffness_diagonal(mesh.points, mesh.tets, lmd, mu), tol=tol)
     sol.close()

@@ -10,7 +10,10 @@
   local nodes in first-touch order, shared nodes in "other ranks' first-touch" order, sorted
   ``Global_shared``.
 
-No GPU work here; nothing in this module imports ``oracle``.
+The O(N) field set-up also exists as HIP kernels (``device_setup_fields`` -> ``saa_setup_fields``,
+``csrc/saa_setup.hip``): that is what :class:`distributed.PartitionedSolver` and ``bench.py`` run, each rank on the
+elements touching its own nodes only; the NumPy closed forms below back the drop-in ``Tools`` functions that hand
+host arrays around like the reference does.  Nothing in this module imports ``oracle``.
 """
 from __future__ import annotations
 
@@ -151,3 +154,114 @@ def build_layouts(cells: np.ndarray, epart: np.ndarray, n_parts: int, n_nodes: i
             dirichlet_dofs=node_to_dof(dloc).astype(np.int32),
             loc_dof_shared=node_to_dof(shared_local)))
     return layouts, global_shared
+
+
+def device_setup_fields(points, cells, rho, fz, device=0):
+    """Lumped mass ``(3n,1)``, pre-assembled load ``(3n,1)`` and shortest edge of the given elements, computed by the
+    HIP set-up kernels (``saa_setup_fields``; replaces ``Global_Assembly_no_bc`` + ``lumping_to_vec`` + ``Meshsize``,
+    ``Data_prepare.py:147,175-176``).  ``cells`` index into ``points``."""
+    import ctypes as C
+
+    from . import _lib
+
+    lib = _lib.load()
+    pts = np.ascontiguousarray(points, dtype=np.float64)
+    tets = np.ascontiguousarray(cells, dtype=np.int32)
+    n = len(pts)
+    lumped, load, edge = np.empty(3 * n), np.empty(3 * n), C.c_double()
+    dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int32)
+    _lib.check(lib.saa_setup_fields(int(device), n, len(tets), pts.ctypes.data_as(dp),
+                                    tets.ctypes.data_as(ip) if len(tets) else None, float(rho), float(fz),
+                                    lumped.ctypes.data_as(dp), load.ctypes.data_as(dp), C.byref(edge)))
+    return lumped.reshape(-1, 1), load.reshape(-1, 1), edge.value
+
+
+def host_setup_fields(points, cells, rho, fz, device=0):
+    """Same triple from the NumPy closed forms (CPU-only tests of the orchestration inject this)."""
+    lumped, load = lumped_mass_and_load(np.asarray(points, dtype=np.float64), np.asarray(cells), rho, fz)
+    return lumped, load, meshsize(np.asarray(points, dtype=np.float64), cells) * np.sqrt(24) / 2.0
+
+
+def dt_from_min_edge(min_edge, E, nu, rho, gamma) -> float:
+    """``gamma * Meshsize / sqrt(E/rho/(1-nu^2))`` with ``Meshsize = 2*min_edge/sqrt(24)`` (``commons.py:79-90``,
+    ``Data_prepare.py:147``), evaluated in the order :func:`cfl_dt` uses."""
+    return gamma * (2.0 * min_edge / np.sqrt(24)) / np.sqrt(E / rho / (1 - nu ** 2))
+
+
+def build_rank_layout(cells: np.ndarray, epart: np.ndarray, rank: int, n_parts: int, n_nodes: int,
+                      dirichlet_nodes: np.ndarray):
+    """THIS rank's :class:`RankLayout` and ``Global_shared`` without building anybody else's: O(Ne) passes over the
+    replicated mesh (``Data_prepare.py:76-79``) plus sorts over this rank's own elements and the other ranks' elements
+    that touch its nodes.  Same orderings as :func:`build_layouts` (the reference's, ``Distributed_tools.py:14-62``)."""
+    cells = np.asarray(cells, dtype=np.int64)
+    epart = np.asarray(epart)
+    elements = np.nonzero(epart == rank)[0]
+    nodes = first_touch_nodes(cells[elements])
+    mine = np.zeros(n_nodes, dtype=bool)
+    mine[nodes] = True
+    # how many parts touch a node: one boolean sweep per part (P is the number of GPUs, small)
+    count = np.zeros(n_nodes, dtype=np.int16)
+    for q in range(n_parts):
+        seen = np.zeros(n_nodes, dtype=bool)
+        seen[cells[epart == q].ravel()] = True
+        count += seen
+    global_shared = np.nonzero(count > 1)[0]                      # sorted union (sort_shared, :44-51)
+    slot_of = np.full(n_nodes, -1, dtype=np.int64)
+    slot_of[global_shared] = np.arange(len(global_shared))
+    # find_shared_nodes (:29-40): sweep the other ranks' first-touch lists in rank order, keep first hits.  A node's
+    # first occurrence in rank q's sweep lies in an element containing it, so the elements of q that touch one of MY
+    # shared nodes carry the whole order.
+    cand = mine & (count > 1)
+    hits = []
+    for q in range(n_parts):
+        if q == rank:
+            continue
+        eq = np.nonzero(epart == q)[0]
+        flat = cells[eq[cand[cells[eq]].any(axis=1)]].ravel()
+        flat = flat[cand[flat]]
+        if flat.size:
+            _, first = np.unique(flat, return_index=True)
+            hits.append(flat[np.sort(first)])
+    if hits:
+        cat = np.concatenate(hits)
+        _, first = np.unique(cat, return_index=True)
+        shared = cat[np.sort(first)]
+    else:
+        shared = np.zeros(0, dtype=np.int64)
+    local_of = np.full(n_nodes, -1, dtype=np.int64)
+    local_of[nodes] = np.arange(len(nodes))
+    is_dirichlet = np.zeros(n_nodes, dtype=bool)
+    is_dirichlet[np.asarray(dirichlet_nodes, dtype=np.int64)] = True
+    shared_local = local_of[shared]
+    dloc = np.nonzero(is_dirichlet[nodes])[0]
+    layout = RankLayout(rank=rank, elements=elements, nodes=nodes, cells_local=local_of[cells[elements]].astype(np.int32),
+                        shared_nodes=shared, shared_local=shared_local.astype(np.int32),
+                        shared_slots=slot_of[shared].astype(np.int32), dirichlet_dofs=node_to_dof(dloc).astype(np.int32),
+                        loc_dof_shared=node_to_dof(shared_local))
+    return layout, global_shared
+
+
+def rank_fields(points, cells, layout: RankLayout, rho, fz, device=0, setup=None):
+    """``l_M``, ``F_rankwise`` ``(3 n_local, 1)`` of this rank (``Data_prepare.py:200-202``: the GLOBAL lumped mass and
+    load restricted to the rank's nodes, so shared nodes carry the contributions of the other ranks' elements too) and
+    the shortest edge among the elements involved.  Only the elements touching this rank's nodes are looked at."""
+    setup = setup or device_setup_fields
+    cells = np.asarray(cells, dtype=np.int64)
+    mine = np.zeros(len(points), dtype=bool)
+    mine[layout.nodes] = True
+    touching = cells[mine[cells].any(axis=1)]
+    sub_nodes = np.unique(touching)
+    sub_of = np.full(len(points), -1, dtype=np.int64)
+    sub_of[sub_nodes] = np.arange(len(sub_nodes))
+    lumped, load, min_edge = setup(np.asarray(points, dtype=np.float64)[sub_nodes], sub_of[touching], rho, fz, device)
+    dof = node_to_dof(sub_of[layout.nodes])
+    return lumped[dof], load[dof], min_edge
+
+
+def rank_problem(points, cells, dirichlet_nodes, epart, rank, n_parts, E, nu, rho, fz, gamma, device=0, setup=None):
+    """Everything rank ``rank`` needs to create its solver (``Data_prepare.py:104-204`` for one rank): its layout,
+    ``Global_shared``, ``l_M`` / ``F_rankwise`` from the set-up kernels and its LOCAL CFL step - the caller takes the
+    minimum over the ranks (``Data_prepare.py:148-154``)."""
+    layout, global_shared = build_rank_layout(cells, epart, rank, n_parts, len(points), dirichlet_nodes)
+    l_M, F_rankwise, min_edge = rank_fields(points, cells, layout, rho, fz, device, setup)
+    return layout, global_shared, l_M, F_rankwise, dt_from_min_edge(min_edge, E, nu, rho, gamma)

@@ -190,6 +190,25 @@ def slab_partition(mesh: Mesh, n_parts: int, axis: int = 0) -> np.ndarray:
     return epart
 
 
+def graph_partition(mesh: Mesh, n_parts: int, return_stats: bool = False):
+    """Element -> part vector from the library's graph partitioner (``saa_part_mesh_kway``: recursive bisection of the
+    dual graph, greedy growing + FM refinement) - the METIS-quality stand-in for ``part_mesh_kway``
+    (``Data_prepare.py:82-101``) on meshes where slabs are poor.  Deterministic: every rank computes the same vector."""
+    import ctypes as C
+
+    from . import _lib
+
+    lib = _lib.load()
+    tets = np.ascontiguousarray(mesh.tets, dtype=np.int32)
+    epart = np.zeros(len(tets), dtype=np.int32)
+    st = _lib.PartitionStats()
+    ip = C.POINTER(C.c_int32)
+    _lib.check(lib.saa_part_mesh_kway(int(n_parts), len(tets), len(mesh.points), tets.ctypes.data_as(ip),
+                                      epart.ctypes.data_as(ip), C.byref(st)))
+    epart = epart.astype(np.int64)
+    return (epart, st.as_dict()) if return_stats else epart
+
+
 def rcb_partition(mesh: Mesh, n_parts: int) -> np.ndarray:
     """Recursive coordinate bisection of element centroids into ``n_parts`` parts."""
     cent = mesh.points[mesh.tets].mean(axis=1)

@@ -5,6 +5,8 @@ the numerics delegated to the CPU oracle.  Lives under tests/: the product never
 import numpy as np
 
 from oracle import fem_oracle as fo
+from synchronization_avoiding_algorithms_amd.fem_setup import host_setup_fields  # noqa: F401  (NumPy closed forms in
+# place of the HIP set-up kernels: passed as PartitionedSolver(setup_fields=...) next to the solver double)
 
 
 class CpuSolverDouble:

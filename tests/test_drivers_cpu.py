@@ -6,7 +6,7 @@ import numpy as np
 import torch
 
 from conftest import load_golden, rel_l2
-from cpu_double import CpuSolverDouble
+from cpu_double import CpuSolverDouble, host_setup_fields
 from synchronization_avoiding_algorithms_amd import drivers, results_io as rio
 
 
@@ -15,7 +15,7 @@ def test_data_prepare_serial_artefacts_and_trajectory(beam_coarse, tmp_path):
     setup = load_golden("serial_setup.npz")
     out = str(tmp_path)
     path, store = drivers.data_prepare(beam_coarse, 100, 1, out, 0, 1, tensor_device=torch.device("cpu"),
-                                       solver_factory=lambda **kw: CpuSolverDouble(**kw))
+                                       solver_factory=lambda **kw: CpuSolverDouble(**kw), setup_fields=host_setup_fields)
     assert store.shape == (330, 100)
     for s in (1, 10, 100):  # column i holds the state after step i+1 (Data_prepare.py:238-240)
         assert rel_l2(store[:, s - 1], g[f"step_{s}"]) < 1e-13 if s > 1 else not store[:, 0].any()
@@ -28,9 +28,9 @@ def test_data_prepare_serial_artefacts_and_trajectory(beam_coarse, tmp_path):
 
 def test_save_every_keeps_the_reference_columns(beam_coarse, tmp_path):
     full = drivers.data_prepare(beam_coarse, 23, 1, str(tmp_path / "a"), 0, 1, tensor_device=torch.device("cpu"),
-                                solver_factory=lambda **kw: CpuSolverDouble(**kw))[1]
+                                solver_factory=lambda **kw: CpuSolverDouble(**kw), setup_fields=host_setup_fields)[1]
     thin = drivers.data_prepare(beam_coarse, 23, 5, str(tmp_path / "b"), 0, 1, tensor_device=torch.device("cpu"),
-                                solver_factory=lambda **kw: CpuSolverDouble(**kw))[1]
+                                solver_factory=lambda **kw: CpuSolverDouble(**kw), setup_fields=host_setup_fields)[1]
     assert thin.shape == (330, 4)  # int(23/5) columns; steps i = 0, 5, 10, 15 (i % save_every == 0)
     assert np.array_equal(thin, full[:, [0, 5, 10, 15]])
 

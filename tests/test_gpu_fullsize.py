@@ -36,14 +36,12 @@ def _build(mesh, n_parts, rank):
 
     lmd, mu = fs.lame(E, NU)
     epart = slab_partition(mesh, n_parts) if n_parts > 1 else np.zeros(len(mesh.tets), dtype=np.int64)
-    layouts, gshared = fs.build_layouts(mesh.tets, epart, n_parts, len(mesh.points), clamp_nodes(mesh))
-    lay = layouts[rank]
-    lumped, fpre = fs.lumped_mass_and_load(mesh.points, mesh.tets, RHO, FZ)
-    dt = fs.cfl_dt(mesh.points, mesh.tets, E, NU, RHO, GAMMA)
-    sol = saa.HipExplicitSolver(mesh.points[lay.nodes], lay.cells_local, lumped[lay.local_dof], fpre[lay.local_dof],
-                                lay.dirichlet_dofs, lmd, mu, dt, ALPHA, shared_local=lay.shared_local,
-                                shared_slots=lay.shared_slots, n_global_shared=len(gshared))
-    return sol, lay, dt, lumped[lay.local_dof], fpre[lay.local_dof], (lmd, mu)
+    lay, gshared, l_M, F, dt = fs.rank_problem(mesh.points, mesh.tets, clamp_nodes(mesh), epart, rank, n_parts, E, NU, RHO,
+                                               FZ, GAMMA, device=0)
+    assert dt == fs.cfl_dt(mesh.points, mesh.tets, E, NU, RHO, GAMMA)  # device shortest edge == host Meshsize path
+    sol = saa.HipExplicitSolver(mesh.points[lay.nodes], lay.cells_local, l_M, F, lay.dirichlet_dofs, lmd, mu, dt, ALPHA,
+                                shared_local=lay.shared_local, shared_slots=lay.shared_slots, n_global_shared=len(gshared))
+    return sol, lay, dt, l_M, F, (lmd, mu)
 
 
 def _operator_properties(sol, K, pts, rng):

@@ -36,27 +36,22 @@ def main():
     from synchronization_avoiding_algorithms_amd import _lib, fem_setup as fs
     from synchronization_avoiding_algorithms_amd.mesh import clamp_nodes, slab_partition, structured_beam
 
+    from bench import build_rank_solver
+
     n = args.refine or N_FOR_GPUS[args.gpus]
     mesh = structured_beam(n)
-    epart = slab_partition(mesh, args.gpus)
-    layouts, gshared = fs.build_layouts(mesh.tets, epart, args.gpus, len(mesh.points), clamp_nodes(mesh))
-    lay = layouts[args.rank]
-    lumped, fpre = fs.lumped_mass_and_load(mesh.points, mesh.tets, RHO, FZ)
-    dt = fs.cfl_dt(mesh.points, mesh.tets, E, NU, RHO, GAMMA)
-    lmd, mu = fs.lame(E, NU)
 
     def make():
-        return saa.HipExplicitSolver(mesh.points[lay.nodes], lay.cells_local, lumped[lay.local_dof],
-                                     fpre[lay.local_dof], lay.dirichlet_dofs, lmd, mu, dt, ALPHA,
-                                     shared_local=lay.shared_local, shared_slots=lay.shared_slots,
-                                     n_global_shared=len(gshared), block_nodes=args.block_nodes,
-                                     threads=args.threads)
+        sol, lay, _, _ = build_rank_solver(mesh, args.gpus, args.rank, 0, args.block_nodes, args.threads)
+        make.lay = lay
+        return sol
 
     lib = _lib.load()
     lib.saa_debug_time_peer.restype = C.c_int
+    plain = make()
+    lay = make.lay
     print(f"rank {args.rank} of {args.gpus}: {len(lay.cells_local)} tets, {len(lay.nodes)} nodes, "
           f"{len(lay.shared_local)} shared nodes", flush=True)
-    plain = make()
     plain.step(200)
     base = plain.time_steps(args.steps) / args.steps * 1e3
     print(f"plain step (no exchange)        : {base:7.2f} us/step   plan {plain.plan_stats()}", flush=True)
