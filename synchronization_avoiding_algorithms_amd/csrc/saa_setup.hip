@@ -90,11 +90,12 @@ __global__ void nodal_fields_kernel(int32_t n_nodes, const int64_t *__restrict__
 
 namespace {
 struct Scratch {
-  void *p[10] = {};
+  void *p[16] = {};
   int n = 0;
   template <typename T>
   hipError_t alloc(T **out, size_t count) {
     void *q = nullptr;
+    if (n >= 16) return hipErrorOutOfMemory;
     const hipError_t e = hipMalloc(&q, count ? count * sizeof(T) : sizeof(T));
     if (e == hipSuccess) p[n++] = q;
     *out = static_cast<T *>(q);

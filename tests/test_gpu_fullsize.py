@@ -36,9 +36,12 @@ def _build(mesh, n_parts, rank):
 
     lmd, mu = fs.lame(E, NU)
     epart = slab_partition(mesh, n_parts) if n_parts > 1 else np.zeros(len(mesh.tets), dtype=np.int64)
-    lay, gshared, l_M, F, dt = fs.rank_problem(mesh.points, mesh.tets, clamp_nodes(mesh), epart, rank, n_parts, E, NU, RHO,
-                                               FZ, GAMMA, device=0)
-    assert dt == fs.cfl_dt(mesh.points, mesh.tets, E, NU, RHO, GAMMA)  # device shortest edge == host Meshsize path
+    lay, gshared, l_M, F, dt_local = fs.rank_problem(mesh.points, mesh.tets, clamp_nodes(mesh), epart, rank, n_parts, E,
+                                                     NU, RHO, FZ, GAMMA, device=0)
+    # dt = min over the ranks (Data_prepare.py:147-154) = the whole mesh's CFL step; here from the device kernel on all
+    # elements, which must give the host Meshsize path's value bit for bit
+    dt = fs.dt_from_min_edge(fs.device_setup_fields(mesh.points, mesh.tets, RHO, FZ)[2], E, NU, RHO, GAMMA)
+    assert dt == fs.cfl_dt(mesh.points, mesh.tets, E, NU, RHO, GAMMA) and dt <= dt_local
     sol = saa.HipExplicitSolver(mesh.points[lay.nodes], lay.cells_local, l_M, F, lay.dirichlet_dofs, lmd, mu, dt, ALPHA,
                                 shared_local=lay.shared_local, shared_slots=lay.shared_slots, n_global_shared=len(gshared))
     return sol, lay, dt, l_M, F, (lmd, mu)
