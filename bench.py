@@ -111,9 +111,10 @@ def cpu_baseline_and_parity(sample_n=10, steps=6000, parity_steps=3000):
     base = dict(one, kind="port")
     if cores > 1:
         try:
-            mp = cpu_baseline_mp.run(cores, sample_n, steps)
-            base = {"value": ne * steps / mp["seconds"], "unit": "element-updates/s", "cores": cores, "kind": "port",
-                    "sample": f"{what} in {cores} x-slabs, one process per slab ({os.cpu_count()} host cores), {steps} "
+            mp_steps = 5 * steps  # ~5-10 s of wall time on 8 cores
+            mp = cpu_baseline_mp.run(cores, sample_n, mp_steps)
+            base = {"value": ne * mp_steps / mp["seconds"], "unit": "element-updates/s", "cores": cores, "kind": "port",
+                    "sample": f"{what} in {cores} x-slabs, one process per slab ({os.cpu_count()} host cores), {mp_steps} "
                               f"steps, per step scipy CSR K.dot + sum of the {mp['n_shared']} shared nodes' forces "
                               f"over the ranks in rank order (shared memory) + numpy update "
                               f"(oracle/cpu_baseline_mp.py), {mp['seconds']:.2f} s",
@@ -171,6 +172,91 @@ def run_preflight(args, world):
         return False
 
 
+def sync_avoiding_leg(part, args, rank, world, ne_total, fence):
+    """BASELINE.json configs[4] the way the reference's workflow produces it (README.md:33-38), all on the GPUs:
+      1. ground truth  - the synchronised run from rest (Data_prepare.py:223-240), recording every rank's shared-dof
+                         history (what Shared_extraction.py slices out) and the full state at the end of every window;
+      2. training      - one LSTM per rank on ITS history (Model_training.py; training.train_on_history: windowing,
+                         [-1, 0] scaling, Adam with 0.998^epoch decay, HIP-graph optimiser step), for a bounded time;
+      3. sync-avoiding - the same simulation again (Online_predictor.py:251-318): n_past*filter_size synchronised
+                         steps, then windows of n_future*filter_size steps in which the shared dofs come from the
+                         rank's model and NO exchange is issued.  Timed: prediction + stepping of the windows.
+    Reported next to the throughput: the rel-L2 distance between the sync-avoiding and the synchronised displacement
+    field (all nodes, all ranks) at the end of each window."""
+    import torch
+    import torch.distributed as dist
+
+    from synchronization_avoiding_algorithms_amd import predictor as pr
+    from synchronization_avoiding_algorithms_amd import training as tr
+
+    n_p, n_f, n_s, hid, windows = 20, 20, args.sa_filter, 50, args.sa_windows
+    warm, win = n_p * n_s, n_f * n_s
+    n_truth = max(args.sa_truth_steps, warm + windows * win)
+    dev, sol = part.tensor_device, part.solver
+    zero = np.zeros(sol.n_dof)
+    width = part.input_size
+    # 1. ground truth
+    sol.set_state(zero, zero, 0.0)
+    truth = torch.zeros((n_truth, width), dtype=torch.float64, device=dev)
+    marks = [warm + (w + 1) * win for w in range(windows)]
+    snaps, pos = [], 0
+    for m in marks + [n_truth]:
+        if m > pos:
+            part.step_synced(m - pos, truth, pos)
+            pos = m
+        if m in marks and len(snaps) < windows:
+            snap = torch.empty(sol.n_dof, dtype=torch.float64, device=dev)
+            sol.get_state_device(snap, None)
+            snaps.append(snap)
+    fence()
+    # 2. one model per rank, trained on its own history
+    t0 = time.perf_counter()
+    with torch.enable_grad():
+        model, smax, smin, tl, vl = tr.train_on_history(truth, n_s, n_p, n_f, cut_off=1.0, seed=1234 + rank,
+                                                        hidden_size=hid, max_seconds=args.sa_train_seconds)
+    fence()
+    train_s = time.perf_counter() - t0
+    groups = truth[::n_s].shape[0] - n_p - n_f + 1
+    del truth
+    predictor = pr.DevicePredictor(model, n_p, n_f, n_s, smax, smin)
+    # 3. the same simulation in sync-avoiding mode
+    sol.set_state(zero, zero, 0.0)
+    hist = torch.zeros((warm + windows * win, width), dtype=torch.float64, device=dev)
+    errs, elapsed, i = [], 0.0, warm
+    with torch.no_grad():
+        part.step_synced(warm, hist, 0)
+        for _ in range(3):  # untimed: the predictor captures its HIP graph on the third call
+            predictor(warm, hist)
+        for w in range(windows):
+            fence()
+            t0 = time.perf_counter()
+            table = predictor(i, hist)
+            part.step_predicted(win, table, 0, hist, i)
+            i += win
+            fence()
+            elapsed += time.perf_counter() - t0
+            cur = torch.empty(sol.n_dof, dtype=torch.float64, device=dev)
+            sol.get_state_device(cur, None)
+            sums = torch.stack([(cur - snaps[w]).square().sum(), snaps[w].square().sum()])
+            dist.all_reduce(sums)  # nodes on an interface count once per holder
+            errs.append(float(torch.sqrt(sums[0] / sums[1]).item()))
+    t = torch.tensor([elapsed, train_s], dtype=torch.float64, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed, train_s = (float(v) for v in t.tolist())
+    finite = torch.tensor([float(torch.isfinite(hist[-1]).all())], device="cuda")
+    dist.all_reduce(finite, op=dist.ReduceOp.MIN)
+    return {"value": ne_total * windows * win / elapsed, "unit": "element-updates/s",
+            "ms_per_step": 1e3 * elapsed / (windows * win), "steps": windows * win, "windows": windows,
+            "n_past": n_p, "n_future": n_f, "filter_size": n_s, "input_size_rank0": width,
+            "rel_l2_vs_synchronised": errs, "state_finite": bool(finite.item()),
+            "training": {"truth_steps": n_truth, "windows": int(groups), "epochs": len(tl), "seconds": train_s,
+                         "train_mse_first_last": [tl[0], tl[-1]], "validation_mse_last": vl[-1], "hidden_size": hid},
+            "note": f"after {warm} synchronised steps every rank's LSTM (trained in this run on the synchronised "
+                    f"history of its own shared dofs) predicts them for {win}-step windows; no collective inside a "
+                    "window; predictor time included; rel_l2_vs_synchronised = whole displacement field against the "
+                    "synchronised run at the end of each window"}
+
+
 def launch_ranks(args):
     """``python bench.py --gpus N`` without a launcher: start the N ranks (one process per GPU) through
     ``torch.distributed.run`` - the reference's whole launch story is ``mpirun -np P python3 ...``
@@ -223,6 +309,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="process-group backend for N > 1 (nccl = RCCL)")
     ap.add_argument("--no-sync-avoiding", action="store_true", help="N > 1: skip the sync-avoiding-mode leg")
+    ap.add_argument("--sa-windows", type=int, default=3, help="sync-avoiding leg: predicted windows that are timed")
+    ap.add_argument("--sa-filter", type=int, default=150, help="sync-avoiding leg: filter_size n_s (Online_predictor.py:59)")
+    ap.add_argument("--sa-truth-steps", type=int, default=30000,
+                    help="sync-avoiding leg: synchronised steps recorded as training data")
+    ap.add_argument("--sa-train-seconds", type=float, default=40.0, help="sync-avoiding leg: training time bound per rank")
     ap.add_argument("--no-rccl-leg", action="store_true",
                     help="N > 1: skip the extra measurement with the RCCL all-reduce when the peer exchange is in use")
     ap.add_argument("--torch-exchange", action="store_true",
@@ -347,42 +438,10 @@ def main():
         raise SystemExit("bench: a wait inside the step kernels timed out")
     sol, gshared, dt = part.solver, part.global_shared, part.dt
 
-    # N > 1: the same partitions in sync-avoiding mode (BASELINE.json configs[4]): after the synchronised warm-up of
-    # n_past*filter_size steps the per-rank LSTM (random-init weights: no trained model ships with the reference)
-    # predicts the shared dofs of each window of n_future*filter_size steps and no collective is issued.
+    # N > 1: the same partitions in sync-avoiding mode (BASELINE.json configs[4]; Online_predictor.py:251-318).
     sync_avoiding = None
     if world > 1 and not args.no_sync_avoiding:
-        from synchronization_avoiding_algorithms_amd import predictor as pr
-
-        n_p, n_f, n_s, hid, windows = 20, 20, 150, 50, 2
-        warm, win = n_p * n_s, n_f * n_s
-        torch.manual_seed(1234 + rank)
-        model = pr.LSTM_encoder_decoder(part.input_size, hid).to(part.tensor_device).eval()
-        predictor = pr.DevicePredictor(model, n_p, n_f, n_s, 1e-3, -1e-3)
-        hist = torch.zeros((warm + windows * win, part.input_size), dtype=torch.float64, device=part.tensor_device)
-        with torch.no_grad():
-            part.step_synced(warm, hist, 0)
-            for _ in range(3):  # untimed: the predictor captures its HIP graph on the third call
-                predictor(warm, hist)
-            fence()
-            t0 = time.perf_counter()
-            i = warm
-            for _ in range(windows):
-                table = predictor(i, hist)
-                part.step_predicted(win, table, 0, hist, i)
-                i += win
-            fence()
-        sa = time.perf_counter() - t0
-        t = torch.tensor([sa], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        sa = float(t.item())
-        finite = torch.tensor([float(torch.isfinite(hist[-1]).all())], device="cuda")
-        dist.all_reduce(finite, op=dist.ReduceOp.MIN)
-        sync_avoiding = {"value": ne_total * windows * win / sa, "unit": "element-updates/s",
-                         "ms_per_step": 1e3 * sa / (windows * win), "steps": windows * win,
-                         "input_size_rank0": part.input_size, "state_finite": bool(finite.item()),
-                         "note": "LSTM-predicted shared dofs (random-init weights), no collective inside the "
-                                 f"{win}-step windows; predictor time included"}
+        sync_avoiding = sync_avoiding_leg(part, args, rank, world, ne_total, fence)
 
     out = None
     if rank == 0:

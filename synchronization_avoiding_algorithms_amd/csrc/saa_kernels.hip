@@ -665,6 +665,7 @@ __global__ void __launch_bounds__(SAA_LB) persistent_steps_kernel(DeviceMesh m, 
       __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const long long t0 = wall_clock64();
       while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (int32_t)gridDim.x) {
+        if (__hip_atomic_load(ap->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) break;  // already decided
         if (wall_clock64() - t0 > ap->timeout_ticks) {  // some workgroup is still queued behind the resident ones
           __hip_atomic_store(ap->err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
           break;

@@ -168,24 +168,30 @@ def _batches(X, Y, batch_size, shuffle, generator=None):
     return [(X[idx[i:i + batch_size]], Y[idx[i:i + batch_size]]) for i in range(0, X.shape[0], batch_size)]
 
 
-def train_rank_model(out_dir=".", rank=0, device=None, batch_size=10, learning_rate=5e-4, hidden_size=50,
-                     filter_size=150, cut_off=0.5, lr_min=5e-7, decay=0.998, T_portion=0.75, n_future=20, n_past=20,
-                     num_epochs=None, seed=None, verbose=False):
-    """``Model_training.py:17-181`` for one rank; returns ``(model_path, train_loss, validation_loss)``."""
-    from .drivers import PATHS
+def windows_from_history(hist, filter_size, n_past, n_future, cut_off=1.0):
+    """The windows of :func:`windowed_dataset` cut from a device-resident shared-dof history ``(n_steps, in)`` - the
+    layout of ``d_sol_shared`` (``Online_predictor.py:260``), i.e. the transpose of the ``Displacement`` dataset
+    ``Shared_extraction.py`` stores - without a round trip through the host."""
+    series = hist[0:int(cut_off * hist.shape[0])][0::filter_size].float()
+    groups = series.shape[0] - n_future - n_past + 1
+    if groups < 1:
+        raise ValueError("history too short for one (n_past, n_future) window")
+    win = series.unfold(0, n_past + n_future, 1).permute(0, 2, 1)
+    return win[:, :n_past, :].contiguous(), win[:, n_past:, :].contiguous()
 
-    device = torch.device(device if device is not None else ("cuda" if torch.cuda.is_available() else "cpu"))
-    gen = None
-    if seed is not None:
-        torch.manual_seed(seed)
-        np.random.seed(seed)
-        gen = torch.Generator().manual_seed(seed)
-    shared = rio.load_int_list(os.path.join(out_dir, PATHS["shared"].format(r=rank)))
-    input_size = 3 * len(shared)
-    traj = rio.load_displacement(os.path.join(out_dir, PATHS["shared_traj"].format(r=rank)))
-    X, Y = windowed_dataset(traj, filter_size, n_past, n_future, cut_off, device)
-    X, Y, _, _ = scale_to_zero_one(X, Y)
-    model = LSTM_encoder_decoder(input_size, hidden_size, 2, True, 0.0, 0.0).to(device)
+
+def fit_windows(X, Y, hidden_size=50, batch_size=10, learning_rate=5e-4, decay=0.998, lr_min=5e-7, T_portion=0.75,
+                num_epochs=None, max_seconds=None, generator=None, verbose=False, rank=0):
+    """The training loop of ``Model_training.py:60-139`` on already scaled windows ``X (groups, n_past, in)``,
+    ``Y (groups, n_future, in)``: Adam, learning rate ``decay**epoch``, random ``T_portion`` training split, shuffled
+    mini-batches, validation on the rest; on a GPU the optimiser step is replayed as a HIP graph.  Stops after
+    ``num_epochs`` (default: until the rate reaches ``lr_min``, ``:65``) or ``max_seconds`` of wall time.
+    Returns ``(model, train_loss, validation_loss)`` (per-epoch means)."""
+    import time
+
+    device = X.device
+    n_future = Y.shape[1]
+    model = LSTM_encoder_decoder(X.shape[2], hidden_size, 2, True, 0.0, 0.0).to(device)
     criterion = nn.MSELoss()
     use_graph = device.type == "cuda" and os.environ.get("SAA_TRAIN_GRAPH", "1") != "0"
     if use_graph:  # capturable Adam with a tensor learning rate: the scheduler's updates reach the graph replays
@@ -205,8 +211,9 @@ def train_rank_model(out_dir=".", rank=0, device=None, batch_size=10, learning_r
     if use_graph and Xtr.shape[0] >= batch_size:
         graphed = GraphedTrainStep(model, criterion, optimizer, n_future, (batch_size,) + tuple(Xtr.shape[1:]),
                                    (batch_size,) + tuple(Ytr.shape[1:]), device)
+    t0 = time.time()
     for epoch in range(num_epochs):
-        tb = _batches(Xtr, Ytr, batch_size, True, gen)
+        tb = _batches(Xtr, Ytr, batch_size, True, generator)
         vb = _batches(Xte, Yte, batch_size, False)
         lt, r2, _, model = model_train(device, model, tb, criterion, optimizer, n_future, graphed=graphed)
         lv, _, _ = model_test(device, model, vb, criterion, n_future) if vb else (float("nan"), 0, 0)
@@ -216,6 +223,46 @@ def train_rank_model(out_dir=".", rank=0, device=None, batch_size=10, learning_r
             print("Epoch: %d, mse training loss: %1.5e, R2 accuracy: %.3f, lr=%g"
                   % (epoch, train_loss[-1], r2 / len(tb), float(optimizer.param_groups[0]["lr"])))
         scheduler.step()
+        if max_seconds is not None and time.time() - t0 > max_seconds:
+            break
+    return model, train_loss, test_loss
+
+
+def train_on_history(hist, filter_size, n_past, n_future, cut_off=1.0, seed=None, **fit_kw):
+    """Train one rank's model straight from the shared-dof history a synchronised run left on the device
+    (``PartitionedSolver.step_synced(n, hist, 0)``): windowing, [-1, 0] scaling, :func:`fit_windows`.
+    Returns ``(model, scale_max, scale_min, train_loss, validation_loss)`` - what ``DevicePredictor`` needs."""
+    gen = None
+    if seed is not None:
+        torch.manual_seed(seed)
+        np.random.seed(seed)
+        gen = torch.Generator().manual_seed(seed)
+    X, Y = windows_from_history(hist, filter_size, n_past, n_future, cut_off)
+    X, Y, smax, smin = scale_to_zero_one(X, Y)
+    model, train_loss, test_loss = fit_windows(X, Y, generator=gen, **fit_kw)
+    return model.eval(), smax, smin, train_loss, test_loss
+
+
+def train_rank_model(out_dir=".", rank=0, device=None, batch_size=10, learning_rate=5e-4, hidden_size=50,
+                     filter_size=150, cut_off=0.5, lr_min=5e-7, decay=0.998, T_portion=0.75, n_future=20, n_past=20,
+                     num_epochs=None, seed=None, verbose=False):
+    """``Model_training.py:17-181`` for one rank; returns ``(model_path, train_loss, validation_loss)``."""
+    from .drivers import PATHS
+
+    device = torch.device(device if device is not None else ("cuda" if torch.cuda.is_available() else "cpu"))
+    gen = None
+    if seed is not None:
+        torch.manual_seed(seed)
+        np.random.seed(seed)
+        gen = torch.Generator().manual_seed(seed)
+    shared = rio.load_int_list(os.path.join(out_dir, PATHS["shared"].format(r=rank)))
+    traj = rio.load_displacement(os.path.join(out_dir, PATHS["shared_traj"].format(r=rank)))
+    if traj.shape[0] != 3 * len(shared):
+        raise ValueError("shared-dof trajectory and shared-node list disagree")
+    X, Y = windowed_dataset(traj, filter_size, n_past, n_future, cut_off, device)
+    X, Y, _, _ = scale_to_zero_one(X, Y)
+    model, train_loss, test_loss = fit_windows(X, Y, hidden_size, batch_size, learning_rate, decay, lr_min, T_portion,
+                                               num_epochs, None, gen, verbose, rank)
     path = os.path.join(out_dir, PATHS["model"].format(r=rank, nB=batch_size, nH=hidden_size, lr=learning_rate,
                                                        ns=filter_size))
     os.makedirs(os.path.dirname(path), exist_ok=True)

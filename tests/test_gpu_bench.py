@@ -24,13 +24,18 @@ def _run(*flags, timeout=900):
 
 def test_two_ranks_launch_themselves_and_print_one_line():
     """N = 2 on the one-GPU box: both ranks share cuda:0, gloo process group (what --same-device is for)."""
-    out = _run("--gpus", "2", "--same-device", "--backend", "gloo", "--refine", "4", "--steps", "40", "--warmup", "10")
+    out = _run("--gpus", "2", "--same-device", "--backend", "gloo", "--refine", "4", "--steps", "40", "--warmup", "10",
+               "--sa-train-seconds", "8", "--sa-truth-steps", "24000")
     assert out["n_gpus"] == 2 and out["steps"] == 40 and out["warmup"] == 10 and out["timed_calls"] >= 1
     assert out["metric"] == "element_updates_per_s" and out["value"] > 0 and out["scaling"] == "weak"
     assert "2 x-slab" in out["config"]["workload"]
     assert abs(out["value"] - 150 * 4 ** 3 * 1e3 / out["ms_per_step"]) < 1e-6 * out["value"]
+    # configs[4]: models trained in the run on the synchronised history, accuracy reported per window
     sa = out["sync_avoiding"]
-    assert sa["value"] > 0 and sa["state_finite"]
+    assert sa["value"] > 0 and sa["state_finite"] and sa["steps"] == 3 * 3000
+    assert len(sa["rel_l2_vs_synchronised"]) == 3 and all(0 <= e < 0.5 for e in sa["rel_l2_vs_synchronised"])
+    tr = sa["training"]
+    assert tr["epochs"] >= 1 and tr["train_mse_first_last"][1] < tr["train_mse_first_last"][0]
 
 
 def test_headline_at_the_drivers_flags_is_warm():

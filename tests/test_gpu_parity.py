@@ -379,3 +379,43 @@ def test_trajectory_recorder_matches_stepwise_downloads(save_every):
     sol.synchronize()
     assert np.array_equal(traj.cpu().numpy(), got)
     sol.close()
+
+
+def test_resident_grid_sizing_several_blocks_per_cu_and_oversized_grids(monkeypatch):
+    """User-forced ``block_nodes`` / ``threads`` put several workgroups of the resident kernel on a CU: the grid is sized
+    by the occupancy query clamped with the scalar-register rule and proved by a census launch (every workgroup checks
+    in and waits, bounded, for all the others).  Fitting grids run resident and agree with the fused kernel; a grid
+    that cannot be co-resident falls back to one launch per step - cleanly, also when the first check is bypassed and
+    the census is what finds out (never a stalled step kernel)."""
+    import time
+
+    from synchronization_avoiding_algorithms_amd.mesh import structured_beam
+
+    mesh = structured_beam(10)
+    fits, _, _, _, _ = _serial_solver(mesh, block_nodes=60, threads=256)
+    st = fits.plan_stats()
+    assert st["n_blocks"] >= 512 and fits.resident_kernel_info()["capable"]      # >= 2 blocks on every CU
+    fits.step(300)
+    a0, an, _ = fits.get_state()
+    fits.set_resident_kernel(False)
+    fits.set_state(np.zeros(fits.n_dof), np.zeros(fits.n_dof), 0.0)
+    fits.step(300)
+    b0, bn, _ = fits.get_state()
+    assert rel_l2(a0, b0) < 1e-12 and rel_l2(an, bn) < 1e-12 and np.abs(b0).max() > 0
+    fits.close()
+
+    mesh = structured_beam(14)  # 76 125 nodes in blocks of 8: ~9500 workgroups, more than the chip can hold at once
+    big, _, _, _, _ = _serial_solver(mesh, block_nodes=8, threads=64)
+    assert big.plan_stats()["n_blocks"] > 256 * 32 and not big.resident_kernel_info()["capable"]
+    big.step(20)
+    ref0 = big.get_state()[0]
+    big.close()
+    monkeypatch.setenv("SAA_RESIDENT_TRUST_GRID", "1")  # let the over-sized grid through to the census
+    t0 = time.time()
+    forced, _, _, _, _ = _serial_solver(mesh, block_nodes=8, threads=64)
+    assert not forced.resident_kernel_info()["capable"]  # the census saw that not everybody was on the chip
+    forced.step(20)
+    forced.synchronize()                                 # no bounded wait fired: the step kernels never started resident
+    assert time.time() - t0 < 20.0
+    assert rel_l2(forced.get_state()[0], ref0) < 1e-13
+    forced.close()
