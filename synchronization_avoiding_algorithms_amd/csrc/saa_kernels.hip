@@ -144,11 +144,13 @@ __device__ __forceinline__ Rec load_rec(const double *rec, unsigned n) {
   const double2 a = r[0], b = r[1], c = r[2];
   return {{a.x, a.y, b.x}, {b.y, c.x, c.y}};
 }
-__device__ __forceinline__ void flush(double *acc, int fstride, unsigned n, int n_owned, const Vec3 &f) {
+// force accumulators: [n_owned][3] doubles (one address computation per node, components at immediate offsets)
+__device__ __forceinline__ void flush(double *acc, unsigned n, int n_owned, const Vec3 &f) {
   if ((int)n < n_owned) {
-    lds_add(acc + n, f.x);
-    lds_add(acc + n + fstride, f.y);
-    lds_add(acc + n + 2 * fstride, f.z);
+    double *a = acc + 3 * n;
+    lds_add(a, f.x);
+    lds_add(a + 1, f.y);
+    lds_add(a + 2, f.z);
   }
 }
 __device__ __forceinline__ Vec3 add3(const Vec3 &a, const Vec3 &b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
@@ -170,7 +172,7 @@ struct NoHook {
 };
 // `mid` runs once per call, half-way through the item (after tet A): the resident kernel issues its halo loads there.
 template <int ABLATE, typename Hook = NoHook>
-__device__ __forceinline__ void item_forces(const uint2 w, const double *rec, double *acc, int fstride, int n_owned,
+__device__ __forceinline__ void item_forces(const uint2 w, const double *rec, double *acc, int n_owned,
                                             double lam, double mu, int tid, double &sink, unsigned long long *T = nullptr,
                                             Hook mid = Hook()) {
   Item it = unpack(w);
@@ -215,7 +217,7 @@ __device__ __forceinline__ void item_forces(const uint2 w, const double *rec, do
     t0 = stamp();
     T[1] += t0 - t1;  // VALU of tet A
   }
-  if (ABLATE != 1) flush(acc, fstride, it.a, n_owned, fa);
+  if (ABLATE != 1) flush(acc, it.a, n_owned, fa);
   else sink += fa.x + fa.y + fa.z;
   mid();
   if (it.pair) {
@@ -238,16 +240,16 @@ __device__ __forceinline__ void item_forces(const uint2 w, const double *rec, do
       t0 = stamp();
       T[3] += t0 - t1;  // VALU of tet B
     }
-    if (ABLATE != 1) flush(acc, fstride, it.b, n_owned, fb);
+    if (ABLATE != 1) flush(acc, it.b, n_owned, fb);
     else sink += fb.x + fb.y + fb.z;
   }
   if (ABLATE == 1) {
     sink += fp.x + fp.y + fp.z + fq.x + fq.y + fq.z + fr.x + fr.y + fr.z;
     return;
   }
-  flush(acc, fstride, it.p, n_owned, fp);
-  flush(acc, fstride, it.q, n_owned, fq);
-  flush(acc, fstride, it.r, n_owned, fr);
+  flush(acc, it.p, n_owned, fp);
+  flush(acc, it.q, n_owned, fq);
+  flush(acc, it.r, n_owned, fr);
   if (ABLATE == 8) T[4] += stamp() - t0;  // remaining atomics: issue + drain
 }
 
@@ -343,8 +345,7 @@ __global__ void __launch_bounds__(SAA_LB) fused_step_kernel(DeviceMesh m, const 
   const BlockDesc bd = m.blocks[pblock];
   const int tid = threadIdx.x, nt = blockDim.x;
   double *rec = lds;                       // [n_owned + n_halo][6]: x y z ux uy uz
-  double *acc = lds + 6 * m.max_local;     // force planes fx | fy | fz, each m.force_stride doubles
-  const int fstride = m.force_stride;
+  double *acc = lds + 6 * m.max_local;     // force accumulators [n_owned][3]
   const int n_own3 = 3 * bd.n_owned, n_halo3 = 3 * bd.n_halo;
   const int64_t base = 3 * (int64_t)bd.node_start;
   const int32_t *hid = m.halo_ids + bd.halo_off;
@@ -375,7 +376,7 @@ __global__ void __launch_bounds__(SAA_LB) fused_step_kernel(DeviceMesh m, const 
       const int n = i / 3, c = i - 3 * n;
       rec[6 * n + c] = ABLATE == 3 ? 1.0 * i : xo[i];
       rec[6 * n + 3 + c] = ABLATE == 3 ? 1e-3 * i : uo[i];
-      acc[n + c * fstride] = 0.0;
+      acc[3 * n + c] = 0.0;
     }
   }
 
@@ -411,7 +412,7 @@ __global__ void __launch_bounds__(SAA_LB) fused_step_kernel(DeviceMesh m, const 
 #pragma unroll
     for (int j = 0; j < kPreConn; ++j)
       if (tid + j * nt < bd.n_interior)
-        item_forces<ABLATE>(cpre[j], rec, acc, fstride, bd.n_owned, m.lambda_, m.mu, tid, sink, T);
+        item_forces<ABLATE>(cpre[j], rec, acc, bd.n_owned, m.lambda_, m.mu, tid, sink, T);
     // (rare) further interior sweeps, software-pipelined: the next connectivity entry is in flight while
     // the current element computes - a dependent global load per sweep would expose its L2 latency
     if (tid + kPreConn * nt < bd.n_interior) {
@@ -419,7 +420,7 @@ __global__ void __launch_bounds__(SAA_LB) fused_step_kernel(DeviceMesh m, const 
       uint2 cur = conn[tid + kPreConn * nt];
       for (int e = tid + kPreConn * nt; e < bd.n_interior; e += nt) {
         const uint2 nxt = conn[min(e + nt, last)];
-        item_forces<ABLATE>(cur, rec, acc, fstride, bd.n_owned, m.lambda_, m.mu, tid, sink, T);
+        item_forces<ABLATE>(cur, rec, acc, bd.n_owned, m.lambda_, m.mu, tid, sink, T);
         cur = nxt;
       }
     }
@@ -459,7 +460,7 @@ __global__ void __launch_bounds__(SAA_LB) fused_step_kernel(DeviceMesh m, const 
   auto finish = [&](int i, double mass, double fpre, double dnv, int32_t tag) {
     if (PEER && (tag & kTagShared)) return;  // updated below from the force summed over the ranks
     const int n = i / 3, c = i - 3 * n;
-    const double f = acc[n + c * fstride];
+    const double f = acc[3 * n + c];
     if (iface != nullptr && (tag & kTagShared)) iface[3 * (int64_t)(tag >> kTagSlotShift) + c] = f;
     double v = cd_update_dof(f, fpre, mass, rec[6 * n + 3 + c], dnv, k);
     if (tag & (1 << c)) v = 0.0;  // d1[Local_Dirichlet] = 0   (Dynamic_solver.py:20)
@@ -471,21 +472,6 @@ __global__ void __launch_bounds__(SAA_LB) fused_step_kernel(DeviceMesh m, const 
     }
     out[base + i] = v;
   };
-  // ---- 4b. early update: nodes met by interior items only are complete (the barrier above drained the
-  //          interior atomics); their stores now overlap the boundary items -----------------------------
-  if (!FORCE_ONLY && ABLATE != 4) {
-    const int n_early3 = 3 * bd.n_early;
-#pragma unroll
-    for (int j = 0; j < kPreOwn; ++j) {
-      const int i = tid + j * nt;
-      if (i < n_early3) finish(i, pm_[j], pf[j], pn[j], ptag[j]);
-    }
-    for (int i = tid + kPreOwn * nt; i < n_early3; i += nt)
-      finish(i, m.mass_node ? m.mass_node[bd.node_start + i / 3] : m.mass[base + i],
-             m.fext_yz ? (i % 3 == 0 ? 0.0 : m.fext_yz[bd.node_start + i / 3]) : m.fext[base + i], dn[base + i],
-             m.tag[bd.node_start + i / 3]);
-  }
-
   if (ABLATE == 8) {
     const unsigned long long t = stamp();
     T[8] = t - tk;  // halo records to LDS + barrier
@@ -496,7 +482,7 @@ __global__ void __launch_bounds__(SAA_LB) fused_step_kernel(DeviceMesh m, const 
     const int last = bd.n_elem - 1;
     for (int e = e_b0; e < bd.n_elem; e += nt) {
       const uint2 nxt = conn[min(e + nt, last)];
-      item_forces<ABLATE>(bcur, rec, acc, fstride, bd.n_owned, m.lambda_, m.mu, tid, sink, T);
+      item_forces<ABLATE>(bcur, rec, acc, bd.n_owned, m.lambda_, m.mu, tid, sink, T);
       bcur = nxt;
     }
   }
@@ -521,7 +507,7 @@ __global__ void __launch_bounds__(SAA_LB) fused_step_kernel(DeviceMesh m, const 
   if (FORCE_ONLY) {
     for (int i = tid; i < n_own3; i += nt) {
       const int n = i / 3, c = i - 3 * n;
-      out[base + i] = acc[n + c * fstride];
+      out[base + i] = acc[3 * n + c];
     }
     return;
   }
@@ -536,17 +522,15 @@ __global__ void __launch_bounds__(SAA_LB) fused_step_kernel(DeviceMesh m, const 
     for (int j = tid; j < n_sh3; j += nt) {
       const int q = sh0 + j / 3, c = j % 3;
       const PeerPushRec r = pmap->push_rec[q];
-      peer_push(pmap, r, q, c, acc[(r.info & 0xffff) + c * fstride], seq);
+      peer_push(pmap, r, q, c, acc[3 * (r.info & 0xffff) + c], seq);
     }
   }
-  const int n_early3 = 3 * bd.n_early;
 #pragma unroll
   for (int j = 0; j < kPreOwn; ++j) {
     const int i = tid + j * nt;
-    if (i >= n_early3 && i < n_own3) finish(i, pm_[j], pf[j], pn[j], ptag[j]);
+    if (i < n_own3) finish(i, pm_[j], pf[j], pn[j], ptag[j]);
   }
   for (int i = tid + kPreOwn * nt; i < n_own3; i += nt)
-    if (i >= n_early3)
     finish(i, m.mass_node ? m.mass_node[bd.node_start + i / 3] : m.mass[base + i],
            m.fext_yz ? (i % 3 == 0 ? 0.0 : m.fext_yz[bd.node_start + i / 3]) : m.fext[base + i], dn[base + i],
            m.tag[bd.node_start + i / 3]);
@@ -559,7 +543,7 @@ __global__ void __launch_bounds__(SAA_LB) fused_step_kernel(DeviceMesh m, const 
       // operands first: their latency overlaps the poll
       const double fe = m.fext[g], ma = m.mass[g], dnv = dn[g];
       const int32_t tag = m.tag[node];
-      const double f = peer_collect(pmap, r, q, c, acc[n + c * fstride], seq);
+      const double f = peer_collect(pmap, r, q, c, acc[3 * n + c], seq);
       double v = cd_update_dof(f, fe, ma, rec[6 * n + 3 + c], dnv, k);  // Dynamic_solver.py:26-32
       if (tag & (1 << c)) v = 0.0;
       out[g] = v;
@@ -682,7 +666,7 @@ __global__ void __launch_bounds__(SAA_LB) persistent_steps_kernel(DeviceMesh m, 
     rec[6 * n + c] = m.xyz[base + i];
     rec[6 * n + 3 + c] = a.g0[base + i];
     dnl[i] = a.g1[base + i];
-    acc[n + c * fstride] = 0.0;
+    acc[3 * n + c] = 0.0;
   }
   for (int n = tid; n < bd.n_owned; n += nt) {
     massl[n] = m.mass_node[bd.node_start + n];
@@ -734,7 +718,7 @@ __global__ void __launch_bounds__(SAA_LB) persistent_steps_kernel(DeviceMesh m, 
       }
     };
     if (tid < n_pre)
-      item_forces<0>(connl[tid], rec, acc, fstride, bd.n_owned, m.lambda_, m.mu, tid, sink, nullptr, fetch);
+      item_forces<0>(connl[tid], rec, acc, bd.n_owned, m.lambda_, m.mu, tid, sink, nullptr, fetch);
     else
       fetch();
     PSTAMP(0)
@@ -783,7 +767,7 @@ __global__ void __launch_bounds__(SAA_LB) persistent_steps_kernel(DeviceMesh m, 
     //         the plan packed each list for the LDS banks from ITS first item, in groups of 16 / 32 lanes.
     for (int p = tid; p < n_post; p += nt) {
       const int e = p < n_ir_pad ? (p < n_ir ? n_pre + p : -1) : bd.n_interior + (p - n_ir_pad);
-      if (e >= 0) item_forces<0>(connl[e], rec, acc, fstride, bd.n_owned, m.lambda_, m.mu, tid, sink);
+      if (e >= 0) item_forces<0>(connl[e], rec, acc, bd.n_owned, m.lambda_, m.mu, tid, sink);
     }
     PSTAMP(4)
     lds_barrier();
@@ -818,7 +802,7 @@ __global__ void __launch_bounds__(SAA_LB) persistent_steps_kernel(DeviceMesh m, 
       }
       dnl[i] = u;
       rec[6 * n + 3 + c] = v;
-      acc[n + c * fstride] = 0.0;
+      acc[3 * n + c] = 0.0;
     };
     // PEER: partial forces of this block's shared nodes leave for the neighbour ranks first; their values are
     // collected after the update of the other nodes (the xGMI flight time hides under it)
@@ -832,15 +816,18 @@ __global__ void __launch_bounds__(SAA_LB) persistent_steps_kernel(DeviceMesh m, 
       for (int j = ltid; j < n_sh3; j += nt) {
         const int q = sh0 + j / 3, c = j % 3;
         const PeerPushRec r = pm->push_rec[q];
-        peer_push(pm, r, q, c, acc[(r.info & 0xffff) + c * fstride], pseq);
+        peer_push(pm, r, q, c, acc[3 * (r.info & 0xffff) + c], pseq);
       }
     }
+    // (one dof at a time: requesting the operands of a lane's two or three dofs up front and interleaving their
+    // division chains was measured - 9.35 against 8.95 us/step at 1M tets, the extra live registers cost more than the
+    // exposed LDS round trips)
     for (int i = ltid; i < n_own3; i += nt) {
       const int n = i / 3, c = i - 3 * n;
       const double u = rec[6 * n + 3 + c];
       const int32_t tag = tagl[n];
       if (PEER && (tag & kTagShared)) continue;  // below, from the force summed over the ranks
-      double v = cd_update_dof(acc[n + c * fstride], c == 0 ? 0.0 : fextl[n], massl[n], u, dnl[i], k);
+      double v = cd_update_dof(acc[i], c == 0 ? 0.0 : fextl[n], massl[n], u, dnl[i], k);
       if (tag & (1 << c)) v = 0.0;  // d1[Local_Dirichlet] = 0   (Dynamic_solver.py:20)
       if (PREDICT && (tag & kTagShared)) {
         // predicted phase: d1[loc_dof_shared] = prediction, recorded as history (Online_predictor.py:298,301)
@@ -856,7 +843,7 @@ __global__ void __launch_bounds__(SAA_LB) persistent_steps_kernel(DeviceMesh m, 
         const int q = sh0 + j / 3, c = j % 3;
         const PeerRecvRec r = pm->recv_rec[q];
         const int n = pm->push_rec[q].info & 0xffff, i = 3 * n + c;
-        const double f = peer_collect(pm, r, q, c, acc[n + c * fstride], pseq);
+        const double f = peer_collect(pm, r, q, c, acc[3 * n + c], pseq);
         const double u = rec[6 * n + 3 + c];
         double v = cd_update_dof(f, c == 0 ? 0.0 : fextl[n], massl[n], u, dnl[i], k);  // Dynamic_solver.py:26-32
         if (tagl[n] & (1 << c)) v = 0.0;

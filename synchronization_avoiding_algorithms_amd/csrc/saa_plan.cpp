@@ -22,7 +22,17 @@ struct Rcb {
   const int64_t *weight = nullptr;      // per node (caller's id): work it brings to its block; null = 1
   void split(int64_t lo, int64_t hi, int32_t nblk) {
     if (nblk <= 1) {
-      std::sort(order.begin() + lo, order.begin() + hi);
+      // inside a block: lexicographic by coordinates.  On structured regions that makes the block-local index a
+      // lattice index, so that translated copies of an element pair differ by one constant in all their vertex slots
+      // - what the clash-free packing of reorder_for_lds is built on - whatever numbering the caller uses.
+      const double *c = xyz;
+      std::sort(order.begin() + lo, order.begin() + hi, [c](int32_t a, int32_t b) {
+        const double *pa = c + 3 * static_cast<int64_t>(a), *pb = c + 3 * static_cast<int64_t>(b);
+        if (pa[0] != pb[0]) return pa[0] < pb[0];
+        if (pa[1] != pb[1]) return pa[1] < pb[1];
+        if (pa[2] != pb[2]) return pa[2] < pb[2];
+        return a < b;
+      });
       block_start.push_back(static_cast<int32_t>(lo));
       return;
     }
@@ -143,8 +153,8 @@ int32_t build_items(const std::vector<uint16_t> &loc, int32_t n_elem, int32_t n_
       if (B[1 + t] == A[1] && B[1 + (t + 1) % 3] == A[3] && B[1 + (t + 2) % 3] == A[2]) return true;
     return false;
   };
-  // an element is interior if all its nodes are owned; pairs never mix the two classes, so that a node met
-  // by interior elements only is complete once the interior items are done (BlockDesc::n_early)
+  // an element is interior if all its nodes are owned; pairs never mix the two classes (interior items run before
+  // the halo records are in LDS)
   auto interior = [&](int32_t e) {
     const uint16_t *c = &loc[4 * static_cast<size_t>(e)];
     return c[0] < n_owned && c[1] < n_owned && c[2] < n_owned && c[3] < n_owned;
@@ -206,6 +216,7 @@ constexpr int kGroupLanes[2][16] = {{0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23,
 struct PackStats {
   double read_mult = 0.0, atomic_mult = 0.0;  // sums of worst multiplicities
   int64_t read_cnt = 0, atomic_cnt = 0;
+  int64_t by_construction = 0;  // items placed in clash-free halves by the pattern-class stage
 };
 
 // Re-order (and re-label) the items of one block part for the LDS traffic of the element phase (LDS image
@@ -241,6 +252,145 @@ int32_t reorder_for_lds(const uint16_t *items, int32_t n_items, int32_t n_owned,
     }
   };
   int32_t done = 0, remaining = n_items;
+  // ---- stage 1: conflict-free halves by construction ------------------------------------------------------------
+  // Two items whose vertex slots differ by the same amount in every slot ("translates": what a structured region of a
+  // mesh is made of) clash in all slots or in none.  So: bring every item into the relabelling with the smallest
+  // difference pattern (slot k minus slot 0, mod 32), sort by pattern, and whenever a pattern class holds items with
+  // all 32 residues of slot 0 mod 32, those 32 items form a half-wave without a single bank clash - residues 0..15 go
+  // to the lanes of the first ds_read_b128 group, 16..31 to the second (distinct mod 16 inside a group for the reads,
+  // distinct mod 32 over the half for the atomics, in every slot at once).  The greedy scan below cannot find these:
+  // its last lanes of a group need one specific residue in each of five slots.  Unstructured regions have no classes
+  // worth the name and fall through to stage 2 unchanged.
+  {
+    struct Cls {
+      uint32_t key;   // 4 x 5-bit differences + pair flag
+      uint8_t res, q;
+      int32_t item;
+    };
+    std::vector<Cls> cls(n_items);
+    for (int32_t e = 0; e < n_items; ++e) {
+      const uint16_t *it = items + 8 * static_cast<size_t>(e);
+      uint32_t best = 0xffffffffu;
+      uint8_t best_q = 0, best_res = 0;
+      for (int q = 0; q < n_syms(it); ++q) {
+        uint16_t v[5];
+        relabel(it, q, v);
+        uint32_t key = it[5] ? 1u : 0u;
+        for (int a = 1; a < 5; ++a) key = (key << 5) | ((v[a] - v[0]) & 31u);
+        if (key < best) {
+          best = key;
+          best_q = static_cast<uint8_t>(q);
+          best_res = static_cast<uint8_t>(v[0] & 31u);
+        }
+      }
+      cls[e] = {best, best_res, best_q, e};
+    }
+    std::sort(cls.begin(), cls.end(), [](const Cls &x, const Cls &y) {
+      if (x.key != y.key) return x.key < y.key;
+      if (x.res != y.res) return x.res < y.res;
+      return x.item < y.item;
+    });
+    std::vector<char> taken(n_items, 0);
+    for (size_t lo = 0; lo < cls.size();) {
+      size_t hi = lo;
+      while (hi < cls.size() && cls[hi].key == cls[lo].key) ++hi;
+      // per residue: the run [first[r], first[r+1]) inside [lo, hi)
+      size_t first[33];
+      {
+        size_t p = lo;
+        for (int r = 0; r < 32; ++r) {
+          while (p < hi && cls[p].res < r) ++p;
+          first[r] = p;
+        }
+        first[32] = hi;
+      }
+      size_t halves = hi - lo;
+      for (int r = 0; r < 32; ++r) halves = std::min(halves, first[r + 1] - first[r]);
+      for (size_t h = 0; h < halves; ++h) {
+        scratch.resize(8 * static_cast<size_t>(done + kHalf), 0);
+        for (int r = 0; r < 32; ++r) {
+          const Cls &c = cls[first[r] + h];
+          const uint16_t *it = items + 8 * static_cast<size_t>(c.item);
+          uint16_t v[5];
+          relabel(it, c.q, v);
+          const int lane = kGroupLanes[r >> 4][r & 15];
+          uint16_t *dst = &scratch[8 * static_cast<size_t>(done + lane)];
+          for (int a = 0; a < kSlots; ++a) dst[a] = v[a];
+          dst[5] = it[5];
+          taken[c.item] = 1;
+        }
+        const int real = (cls[lo].key >> 20) ? 5 : 4;  // pair flag sits above the four 5-bit fields
+        st.read_mult += 2.0 * real;
+        st.read_cnt += 2 * real;
+        st.atomic_mult += real;
+        st.atomic_cnt += real;
+        done += kHalf;
+        remaining -= kHalf;
+        st.by_construction += kHalf;
+      }
+      lo = hi;
+    }
+    // second tier, on what the classes have left: 16 items of one class with all residues mod 16 make a clash-free
+    // ds_read_b128 group; two such groups (of whatever classes) share a half-wave, where only their atomics may still
+    // meet (mod 32 across the half) - counted honestly below
+    struct Grp {
+      int32_t item[16];
+      uint8_t q[16];
+    };
+    std::vector<Grp> groups;
+    for (size_t lo = 0; lo < cls.size();) {
+      size_t hi = lo;
+      while (hi < cls.size() && cls[hi].key == cls[lo].key) ++hi;
+      std::vector<int32_t> by_res[16];
+      for (size_t i = lo; i < hi; ++i)
+        if (!taken[cls[i].item]) by_res[cls[i].res & 15].push_back(static_cast<int32_t>(i));
+      size_t n_grp = hi - lo;
+      for (auto &b : by_res) n_grp = std::min(n_grp, b.size());
+      for (size_t h = 0; h < n_grp; ++h) {
+        Grp gp;
+        for (int r = 0; r < 16; ++r) {
+          const Cls &c = cls[by_res[r][h]];
+          gp.item[r] = c.item;
+          gp.q[r] = c.q;
+        }
+        groups.push_back(gp);
+      }
+      lo = hi;
+    }
+    for (size_t g2 = 0; g2 + 1 < groups.size(); g2 += 2) {
+      scratch.resize(8 * static_cast<size_t>(done + kHalf), 0);
+      uint8_t cnt_at[kSlots][32] = {};
+      int max_at[kSlots] = {}, real_max = 4;
+      for (int g = 0; g < 2; ++g)
+        for (int r = 0; r < 16; ++r) {
+          const int32_t e = groups[g2 + g].item[r];
+          const uint16_t *it = items + 8 * static_cast<size_t>(e);
+          uint16_t v[5];
+          relabel(it, groups[g2 + g].q[r], v);
+          uint16_t *dst = &scratch[8 * static_cast<size_t>(done + kGroupLanes[g][r])];
+          const int real = it[5] ? 5 : 4;
+          real_max = std::max(real_max, real);
+          for (int a = 0; a < kSlots; ++a) {
+            dst[a] = v[a];
+            if (a < real && v[a] < n_owned) max_at[a] = std::max<int>(max_at[a], ++cnt_at[a][v[a] & 31]);
+          }
+          dst[5] = it[5];
+          taken[e] = 1;
+        }
+      st.read_mult += 2.0 * real_max;
+      st.read_cnt += 2 * real_max;
+      for (int a = 0; a < real_max; ++a)
+        if (max_at[a] > 0) {
+          st.atomic_mult += max_at[a];
+          ++st.atomic_cnt;
+        }
+      done += kHalf;
+      remaining -= kHalf;
+      st.by_construction += kHalf;
+    }
+    pool.erase(std::remove_if(pool.begin(), pool.end(), [&](int32_t e) { return taken[e] != 0; }), pool.end());
+  }
+  // ---- stage 2: greedy packing of what is left ----------------------------------------------------------------
   while (remaining > 0) {
     const int32_t cap = kHalf;
     scratch.resize(8 * static_cast<size_t>(done + kHalf), 0);
@@ -429,31 +579,6 @@ bool build_once(int32_t n_nodes, int32_t n_elems, const double *xyz, const int32
       node_block[i] = b;
     }
 
-  // Within a block, nodes that only meet elements lying entirely inside the block come first ("early"):
-  // their force is complete after the interior items, so their update overlaps the boundary items.
-  std::vector<int32_t> n_early(n_blocks, 0);
-  {
-    std::vector<char> late(n_nodes, 0);  // indexed by internal id
-    for (int32_t e = 0; e < n_elems; ++e) {
-      int32_t g[4];
-      for (int a = 0; a < 4; ++a) g[a] = plan.old_to_new[tets[4 * static_cast<int64_t>(e) + a]];
-      const int32_t b0 = node_block[g[0]];
-      if (node_block[g[1]] != b0 || node_block[g[2]] != b0 || node_block[g[3]] != b0)
-        for (int a = 0; a < 4; ++a) late[g[a]] = 1;
-    }
-    std::vector<int32_t> reordered(n_nodes);
-    for (int32_t b = 0; b < n_blocks; ++b) {
-      int32_t w = block_start[b];
-      for (int32_t i = block_start[b]; i < block_start[b + 1]; ++i)
-        if (!late[i]) reordered[w++] = plan.new_to_old[i];
-      n_early[b] = w - block_start[b];
-      for (int32_t i = block_start[b]; i < block_start[b + 1]; ++i)
-        if (late[i]) reordered[w++] = plan.new_to_old[i];
-    }
-    plan.new_to_old.swap(reordered);
-    for (int32_t i = 0; i < n_nodes; ++i) plan.old_to_new[plan.new_to_old[i]] = i;  // node_block is unchanged
-  }
-
   // element copies per block: an element belongs to every block owning one of its nodes
   std::vector<int64_t> off(n_blocks + 1, 0);
   auto blocks_of = [&](int32_t e, int32_t out[4]) {
@@ -589,7 +714,7 @@ bool build_once(int32_t n_nodes, int32_t n_elems, const double *xyz, const int32
     d.elem_off = static_cast<int32_t>(pos);
     d.n_elem = n_items[b];
     d.n_interior = n_interior[b];
-    d.n_early = n_early[b];
+    d.reserved = 0;
     std::copy(block_items[b].begin(), block_items[b].end(), plan.conn.begin() + 8 * pos);
     pos += n_items[b];
     plan.n_pairs += n_paired[b];
@@ -608,6 +733,7 @@ bool build_once(int32_t n_nodes, int32_t n_elems, const double *xyz, const int32
     tot.read_cnt += st.read_cnt;
     tot.atomic_mult += st.atomic_mult;
     tot.atomic_cnt += st.atomic_cnt;
+    tot.by_construction += st.by_construction;
   }
   plan.lds_conflict_factor = tot.read_cnt ? tot.read_mult / tot.read_cnt : 1.0;
   if (getenv("SAA_PLAN_DEBUG")) {
@@ -629,9 +755,10 @@ bool build_once(int32_t n_nodes, int32_t n_elems, const double *xyz, const int32
   }
   if (getenv("SAA_PLAN_DEBUG"))
     fprintf(stderr,
-            "plan: %lld element copies in %lld items (%lld pairs); read conflict factor %.3f, atomic %.3f (%u threads)\n",
+            "plan: %lld element copies in %lld items (%lld pairs, %lld in clash-free halves by construction); read conflict "
+            "factor %.3f, atomic %.3f (%u threads)\n",
             static_cast<long long>(plan.n_elem_copies), static_cast<long long>(plan.n_items),
-            static_cast<long long>(plan.n_pairs), plan.lds_conflict_factor,
+            static_cast<long long>(plan.n_pairs), static_cast<long long>(tot.by_construction), plan.lds_conflict_factor,
             tot.atomic_cnt ? tot.atomic_mult / tot.atomic_cnt : 1.0, n_thr);
   return true;
 }

@@ -21,8 +21,7 @@ struct BlockDesc {
   int32_t elem_off;    // offset into conn, in work items
   int32_t n_elem;      // work items of the block (pairs of face-adjacent elements, or single elements)
   int32_t n_interior;  // items [0,n_interior) touch owned nodes only; the rest need halo records
-  int32_t n_early;     // owned nodes [0,n_early) are touched by interior items only: their forces are final
-                       // (and their update can run) before the boundary items start
+  int32_t reserved;    // (keeps the descriptor at 32 bytes)
 };
 
 // LDS image of a block (doubles): node records [n_local][6] = x y z ux uy uz (48 B, 16-B aligned: three

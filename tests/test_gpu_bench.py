@@ -33,7 +33,8 @@ def test_two_ranks_launch_themselves_and_print_one_line():
     # configs[4]: models trained in the run on the synchronised history, accuracy reported per window
     sa = out["sync_avoiding"]
     assert sa["value"] > 0 and sa["state_finite"] and sa["steps"] == 3 * 3000
-    assert len(sa["rel_l2_vs_synchronised"]) == 3 and all(0 <= e < 0.5 for e in sa["rel_l2_vs_synchronised"])
+    # (a model trained for 8 seconds: the bound only says that the windows follow the synchronised run)
+    assert len(sa["rel_l2_vs_synchronised"]) == 3 and all(0 <= e < 0.5 for e in sa["rel_l2_vs_synchronised"]), sa
     tr = sa["training"]
     assert tr["epochs"] >= 1 and tr["train_mse_first_last"][1] < tr["train_mse_first_last"][0]
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Folds rocprofv3 --pmc outputs into profiles/r01_pmc_summary.json.
+"""Folds rocprofv3 --pmc outputs into profiles/r02_pmc_summary.json (--out=<file> for another).
 
-    python tools/pmc_summary.py <key> <rocprof output dir> [<kernel name substring>] [--steps-only N]
+    python tools/pmc_summary.py <key> <rocprof output dir> [<kernel name substring>] [--grid=G] [--out=profiles/x.json]
 
 For every counter in the directory's *_counter_collection.csv files: mean value per dispatch of the kernels whose
 name contains the substring (default: "step").  With --grid G only dispatches of that grid size (threads) count,
@@ -36,7 +36,10 @@ def main():
                 d = acc.setdefault(row["Counter_Name"], {"sum": 0.0, "n": 0, "kernel": row["Kernel_Name"][:80]})
                 d["sum"] += float(row["Counter_Value"])
                 d["n"] += 1
-    out_path = os.path.join(REPO, "profiles", "r01_pmc_summary.json")
+    out_path = os.path.join(REPO, "profiles", "r02_pmc_summary.json")
+    for a in sys.argv[1:]:
+        if a.startswith("--out="):
+            out_path = os.path.join(REPO, a.split("=", 1)[1])
     try:
         with open(out_path) as fh:
             summary = json.load(fh)
