@@ -80,7 +80,7 @@ typedef struct saa_plan_stats {
 } saa_plan_stats;
 
 const char *saa_last_error(void);
-/* Library / ABI version; bumps when this header changes (2: peer exchange and resident-kernel entry points; 3: loop-back attach; 4: partitioner and set-up kernels). */
+/* Library / ABI version; bumps when this header changes (2: peer exchange and resident-kernel entry points; 3: loop-back attach; 4: partitioner and set-up kernels; 5: deterministic mode). */
 int32_t saa_abi_version(void);
 
 /* Element partition, one part per rank / GPU: the role of `_, epart = part_mesh_kway(size, eptr, eind)` (mgmetis /
@@ -236,6 +236,15 @@ int saa_resident_kernel_info(const saa_solver *s, int32_t *capable, int32_t *lds
 /* enable = 0: keep this handle on one launch per step (for callers that know the device is shared with other
  * processes: workgroups of a resident kernel that wait for another process' kernel only advance by time-slicing). */
 int saa_set_resident_kernel(saa_solver *s, int32_t enable);
+
+/* Deterministic mode.  The step kernels accumulate the element forces of a node with LDS floating-point atomics, whose
+ * order is free: f_int - and with it the trajectory - differs in the last bits from run to run (the same class of
+ * difference as the reference's own dependence on partition and node numbering).  enable = 1 switches
+ * this handle to a two-kernel form of the step without atomics: every work item writes its force vectors to memory and every
+ * node adds the vectors addressed to it in a fixed order.  Same arithmetic per element, bit-identical results from run to
+ * run; several times slower (a verification mode).  Covers saa_step, saa_step_begin/finish, saa_step_synced,
+ * saa_step_predicted and saa_internal_force*; saa_step_peer is refused while it is on. */
+int saa_set_deterministic(saa_solver *s, int32_t enable);
 
 /* Blocks until all work enqueued for this handle has finished. */
 int saa_synchronize(saa_solver *s);

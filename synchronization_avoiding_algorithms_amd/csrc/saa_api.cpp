@@ -131,6 +131,12 @@ struct saa_solver {
   double *rec_traj = nullptr;
   int64_t rec_cols = 0, rec_index = 0;
   int32_t rec_every = 1;
+  // deterministic mode (saa_set_deterministic)
+  bool det = false;
+  DevBuf<double> det_force;
+  DevBuf<int64_t> det_off;
+  DevBuf<int32_t> det_contrib;
+  saa::DetLists detl{};
   double *ps_dbg = nullptr; // diagnostic builds (-DSAA_PERSIST_STAMPS): where the per-wave cycle counts go
   // direct peer exchange (saa_peer_export / saa_peer_attach)
   void *peer_mem = nullptr;          // this rank's exported allocation: flags + inbox (fine-grained)
@@ -169,6 +175,7 @@ struct saa_solver {
     for (auto &b : dbuf) b.release();
     for (auto &b : scratch) b.release();
     ps_entries.release(); ps_err.release(); ps_args.release();
+    det_force.release(); det_off.release(); det_contrib.release();
     for (void *q : peer_open) (void)hipIpcCloseMemHandle(q);
     peer_open.clear();
     if (peer_mem) (void)hipFree(peer_mem);
@@ -387,7 +394,7 @@ constexpr int32_t kPersistChunk = 1000;
 int try_persistent_steps(saa_solver *s, int32_t nsteps, const double *table_dev, int64_t table_row0, double *hist_dev,
                          int64_t hist_row0, int32_t *n_done, bool peer = false) {
   *n_done = 0;
-  if (!s->ps_capable || !s->ps_enabled || nsteps < kPersistMinSteps || !s->mesh.mass_node || !s->mesh.fext_yz)
+  if (s->det || !s->ps_capable || !s->ps_enabled || nsteps < kPersistMinSteps || !s->mesh.mass_node || !s->mesh.fext_yz)
     return SAA_OK;
   int32_t chunk = kPersistChunk;
   if (const char *env = std::getenv("SAA_PERSIST_CHUNK")) chunk = std::max(kPersistMinSteps, std::atoi(env));
@@ -442,6 +449,24 @@ int try_persistent_steps(saa_solver *s, int32_t nsteps, const double *table_dev,
   return SAA_OK;
 }
 
+// one step kernel (or pair of kernels in deterministic mode) from d^n, d^(n-1) into d^(n+1)
+void launch_step(saa_solver *s, double *iface, const double *table_row, double *hist_row) {
+  if (s->det)
+    saa::launch_det_step(s->mesh, s->detl, s->threads, s->lds_bytes, s->stream, s->dbuf[s->i0].p, s->dbuf[s->in_].p,
+                         s->dbuf[s->i1].p, iface, table_row, hist_row, s->consts, false);
+  else
+    saa::launch_fused_step(s->mesh, s->threads, s->lds_bytes, s->stream, s->dbuf[s->i0].p, s->dbuf[s->in_].p,
+                           s->dbuf[s->i1].p, iface, table_row, hist_row, s->consts);
+}
+
+void launch_force(saa_solver *s, const double *d, double *f) {
+  if (s->det)
+    saa::launch_det_step(s->mesh, s->detl, s->threads, s->lds_bytes, s->stream, d, d, f, nullptr, nullptr, nullptr,
+                         saa::StepConsts{}, true);
+  else
+    saa::launch_force_only(s->mesh, s->threads, s->lds_bytes, s->stream, d, f);
+}
+
 int check_launch() {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(SAA_E_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
@@ -454,7 +479,7 @@ extern "C" {
 
 const char *saa_last_error(void) { return g_last_error.c_str(); }
 
-int32_t saa_abi_version(void) { return 4; }  // 3: saa_peer_attach_loopback; 4: saa_part_mesh_kway, saa_setup_fields
+int32_t saa_abi_version(void) { return 5; }  // 4: saa_part_mesh_kway, saa_setup_fields; 5: saa_set_deterministic
 
 int saa_plan_host_stats(int32_t n_nodes, int32_t n_elems, const double *xyz, const int32_t *tets,
                         int32_t block_nodes, saa_plan_stats *out) {
@@ -745,7 +770,7 @@ int saa_internal_force(saa_solver *s, const double *d_host, double *f_host) {
   HIP_TRY(hipSetDevice(s->device));
   if (int rc = ensure_scratch(s, 2)) return rc;
   if (int rc = upload_permuted(s, d_host, s->scratch[0].p)) return rc;
-  saa::launch_force_only(s->mesh, s->threads, s->lds_bytes, s->stream, s->scratch[0].p, s->scratch[1].p);
+  launch_force(s, s->scratch[0].p, s->scratch[1].p);
   if (int rc = check_launch()) return rc;
   return download_permuted(s, s->scratch[1].p, f_host);
 }
@@ -755,7 +780,7 @@ int saa_internal_force_device(saa_solver *s, const double *d_dev, double *f_dev)
   HIP_TRY(hipSetDevice(s->device));
   if (int rc = ensure_scratch(s, 2)) return rc;
   saa::launch_permute(s->plan.n_nodes, s->new_to_old.p, s->stream, d_dev, s->scratch[0].p);
-  saa::launch_force_only(s->mesh, s->threads, s->lds_bytes, s->stream, s->scratch[0].p, s->scratch[1].p);
+  launch_force(s, s->scratch[0].p, s->scratch[1].p);
   saa::launch_unpermute(s->plan.n_nodes, s->new_to_old.p, s->stream, s->scratch[1].p, f_dev);
   return check_launch();
 }
@@ -783,8 +808,7 @@ int saa_step(saa_solver *s, int32_t nsteps) {
   if (int rc = try_persistent_steps(s, nsteps, nullptr, 0, nullptr, 0, &k0)) return rc;
   for (int32_t k = k0; k < nsteps; ++k) {
     s->set_ramp();
-    saa::launch_fused_step(s->mesh, s->threads, s->lds_bytes, s->stream, s->dbuf[s->i0].p, s->dbuf[s->in_].p,
-                           s->dbuf[s->i1].p, nullptr, nullptr, nullptr, s->consts);
+    launch_step(s, nullptr, nullptr, nullptr);
     s->rotate();
     s->tn = s->tn + s->consts.dt;  // Data_prepare.py:235
   }
@@ -805,8 +829,7 @@ int saa_step_begin(saa_solver *s) {
     return fail(SAA_E_STATE, "saa_step_begin: no interface buffer set");
   HIP_TRY(hipSetDevice(s->device));
   s->set_ramp();
-  saa::launch_fused_step(s->mesh, s->threads, s->lds_bytes, s->stream, s->dbuf[s->i0].p, s->dbuf[s->in_].p,
-                         s->dbuf[s->i1].p, s->iface, nullptr, nullptr, s->consts);
+  launch_step(s, s->iface, nullptr, nullptr);
   s->pending = true;
   return check_launch();
 }
@@ -862,8 +885,7 @@ int saa_step_synced(saa_solver *s, int32_t nsteps, double *hist_dev, int64_t his
   const int64_t width = 3 * static_cast<int64_t>(s->n_shared);
   for (int32_t k = 0; k < nsteps; ++k) {
     s->set_ramp();
-    saa::launch_fused_step(s->mesh, s->threads, s->lds_bytes, s->stream, s->dbuf[s->i0].p, s->dbuf[s->in_].p,
-                           s->dbuf[s->i1].p, s->iface, nullptr, nullptr, s->consts);
+    launch_step(s, s->iface, nullptr, nullptr);
     if (count > 0) {
       const int rc = g_nccl.AllReduce(s->iface, s->iface, count, kNcclDouble, kNcclSum, s->comm, s->stream);
       if (rc != 0) return fail(SAA_E_HIP, std::string("ncclAllReduce: ") + g_nccl.GetErrorString(rc));
@@ -1144,6 +1166,7 @@ int saa_peer_selftest(saa_solver *s, int32_t *ok) {
 int saa_step_peer(saa_solver *s, int32_t nsteps, double *hist_dev, int64_t hist_row0) {
   if (!s || nsteps < 0 || (hist_dev && hist_row0 < 0)) return fail(SAA_E_ARG, "saa_step_peer: bad argument");
   if (!s->peer_ready) return fail(SAA_E_STATE, "saa_step_peer: saa_peer_attach has not been called");
+  if (s->det) return fail(SAA_E_STATE, "saa_step_peer: not available in deterministic mode (use saa_step_begin/finish)");
   if (s->pending) return fail(SAA_E_STATE, "saa_step_peer: a synchronised step is in flight");
   HIP_TRY(hipSetDevice(s->device));
   const int64_t width = 3 * static_cast<int64_t>(s->n_shared);
@@ -1176,9 +1199,8 @@ int saa_step_predicted(saa_solver *s, int32_t nsteps, const double *table_dev, i
   for (int32_t k = k0; k < nsteps; ++k) {
     s->set_ramp();
     // halo overwrite + history record are fused into the step kernel's epilogue (one launch per step)
-    saa::launch_fused_step(s->mesh, s->threads, s->lds_bytes, s->stream, s->dbuf[s->i0].p, s->dbuf[s->in_].p,
-                           s->dbuf[s->i1].p, nullptr, s->n_shared > 0 ? table_dev + (table_row0 + k) * width : nullptr,
-                           hist_dev ? hist_dev + (hist_row0 + k) * width : nullptr, s->consts);
+    launch_step(s, nullptr, s->n_shared > 0 ? table_dev + (table_row0 + k) * width : nullptr,
+                hist_dev ? hist_dev + (hist_row0 + k) * width : nullptr);
     s->rotate();
     s->tn = s->tn + s->consts.dt;
   }
@@ -1218,6 +1240,42 @@ int saa_set_recorder(saa_solver *s, double *traj_dev, int64_t n_cols, int32_t sa
   s->rec_cols = traj_dev ? n_cols : 0;
   s->rec_every = traj_dev ? save_every : 1;
   s->rec_index = traj_dev ? next_step_index : 0;
+  return SAA_OK;
+}
+
+int saa_set_deterministic(saa_solver *s, int32_t enable) {
+  if (!s) return fail(SAA_E_ARG, "saa_set_deterministic: null handle");
+  if (s->pending) return fail(SAA_E_STATE, "saa_set_deterministic: a synchronised step is in flight");
+  HIP_TRY(hipSetDevice(s->device));
+  if (enable && !s->det_off.p) {
+    // per owned node (internal order): the item-force vectors addressed to it, ascending by item and slot
+    const saa::Plan &plan = s->plan;
+    std::vector<int64_t> off(static_cast<size_t>(plan.n_nodes) + 1, 0);
+    auto each = [&](auto &&fn) {
+      for (const saa::BlockDesc &b : plan.blocks)
+        for (int32_t e = 0; e < b.n_elem; ++e) {
+          const uint16_t *it = &plan.conn[8 * static_cast<size_t>(b.elem_off + e)];
+          if (it[5] == 2) continue;  // null item
+          const int slots = it[5] == 1 ? 5 : 4;
+          for (int a = 0; a < slots; ++a)
+            if (it[a] < b.n_owned) fn(b.node_start + it[a], (b.elem_off + e) * 8 + a);
+        }
+    };
+    each([&](int32_t node, int32_t) { ++off[node + 1]; });
+    for (int32_t i = 0; i < plan.n_nodes; ++i) off[i + 1] += off[i];
+    if (plan.n_items >= (1ll << 28)) return fail(SAA_E_CAPACITY, "saa_set_deterministic: too many work items");
+    std::vector<int32_t> contrib(static_cast<size_t>(off[plan.n_nodes]));
+    std::vector<int64_t> cur(off.begin(), off.end() - 1);
+    each([&](int32_t node, int32_t id) { contrib[cur[node]++] = id; });
+    HIP_TRY(s->det_off.upload(off));
+    HIP_TRY(s->det_contrib.upload(contrib.empty() ? std::vector<int32_t>(1, 0) : contrib));
+    HIP_TRY(s->det_force.alloc(15 * static_cast<size_t>(std::max<int64_t>(plan.n_items, 1))));
+    HIP_TRY(saa::configure_det_kernels(s->lds_bytes));
+    s->detl.item_force = s->det_force.p;
+    s->detl.contrib_off = s->det_off.p;
+    s->detl.contrib = s->det_contrib.p;
+  }
+  s->det = enable != 0;
   return SAA_OK;
 }
 

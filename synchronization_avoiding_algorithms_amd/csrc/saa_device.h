@@ -35,6 +35,13 @@ struct StepConsts {
   double dt, dt2, half_dt, alpha, half_alpha, ramp;
 };
 
+// Deterministic mode: per-item force vectors and, per owned node (internal order), the list of vectors addressed to it.
+struct DetLists {
+  double *item_force;          // (n_items, 5 slots a p q r b, 3)
+  const int64_t *contrib_off;  // (n_nodes + 1)
+  const int32_t *contrib;      // global item index * 8 + slot, ascending
+};
+
 struct SharedMap {
   const int32_t *node;          // (n_shared) internal node id, caller's shared order
   const int32_t *slot;          // (n_shared) interface slot
@@ -128,6 +135,11 @@ hipError_t launch_persistent_steps(const DeviceMesh &m, int threads, int lds_byt
                                    PersistArgs *args_dev, const PersistArgs &a, int mode);
 
 hipError_t configure_kernels(int lds_bytes);
+hipError_t configure_det_kernels(int lds_bytes);
+// One step (or, force_only, f = K d into `out`) without floating-point atomics: item kernel + node kernel.
+void launch_det_step(const DeviceMesh &m, const DetLists &det, int threads, int lds_bytes, hipStream_t st, const double *d0,
+                     const double *dn, double *out, double *iface, const double *table_row, double *hist_row,
+                     const StepConsts &k, bool force_only);
 void launch_fused_step(const DeviceMesh &m, int threads, int lds_bytes, hipStream_t st, const double *d0,
                        const double *dn, double *d1, double *iface, const double *table_row, double *hist_row,
                        const StepConsts &k);

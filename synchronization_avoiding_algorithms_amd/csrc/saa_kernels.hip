@@ -865,6 +865,88 @@ __global__ void __launch_bounds__(SAA_LB) persistent_steps_kernel(DeviceMesh m, 
   if (sink == 12345.678) acc[0] = sink;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Deterministic mode (saa_set_deterministic): the same element arithmetic, but no floating-point atomics.  The item
+// kernel writes the five force vectors of every item to global memory; the node kernel adds, for every owned node, the
+// vectors addressed to it in a FIXED order (ascending item, then slot: the list the host built from the plan) and
+// applies the update.  Bit-identical results run after run and on every device, at several times the cost of the fused
+// kernel (78 MB of item forces per step at 1M tets): a verification mode ("hard parts").
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(SAA_LB) det_items_kernel(DeviceMesh m, const double *__restrict__ d0,
+                                                           double *__restrict__ item_force) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const BlockDesc bd = m.blocks[blockIdx.x];
+  const int tid = threadIdx.x, nt = blockDim.x;
+  double *rec = lds;
+  const int64_t base = 3 * (int64_t)bd.node_start;
+  const int32_t *hid = m.halo_ids + bd.halo_off;
+  for (int i = tid; i < 3 * bd.n_owned; i += nt) {
+    const int n = i / 3, c = i - 3 * n;
+    rec[6 * n + c] = m.xyz[base + i];
+    rec[6 * n + 3 + c] = d0[base + i];
+  }
+  for (int i = tid; i < 3 * bd.n_halo; i += nt) {
+    const int n = i / 3, c = i - 3 * n;
+    const int64_t g = 3 * (int64_t)hid[n] + c;
+    rec[6 * (bd.n_owned + n) + c] = m.xyz[g];
+    rec[6 * (bd.n_owned + n) + 3 + c] = d0[g];
+  }
+  __syncthreads();
+  for (int e = tid; e < bd.n_elem; e += nt) {
+    const Item it = unpack(m.conn[bd.elem_off + e]);
+    if (it.null) continue;
+    // exactly the evaluation order of item_forces: A as (p; a, r, q), B as (p; b, q, r), face forces summed in registers
+    const Rec rp = load_rec(rec, it.p), rq = load_rec(rec, it.q), rr = load_rec(rec, it.r), ra = load_rec(rec, it.a);
+    Vec3 fa, fp, fq, fr, fb = {0, 0, 0};
+    tet_forces(rp.x, ra.x, rr.x, rq.x, rp.u, ra.u, rr.u, rq.u, m.lambda_, m.mu, fa, fr, fq);
+    fp = neg_sum3(fa, fr, fq);
+    if (it.pair) {
+      const Rec rb = load_rec(rec, it.b);
+      Vec3 gq, gr;
+      tet_forces(rp.x, rb.x, rq.x, rr.x, rp.u, rb.u, rq.u, rr.u, m.lambda_, m.mu, fb, gq, gr);
+      fp = add3(fp, neg_sum3(fb, gq, gr));
+      fq = add3(fq, gq);
+      fr = add3(fr, gr);
+    }
+    double *o = item_force + 15 * (int64_t)(bd.elem_off + e);
+    o[0] = fa.x; o[1] = fa.y; o[2] = fa.z; o[3] = fp.x; o[4] = fp.y; o[5] = fp.z; o[6] = fq.x; o[7] = fq.y; o[8] = fq.z;
+    o[9] = fr.x; o[10] = fr.y; o[11] = fr.z; o[12] = fb.x; o[13] = fb.y; o[14] = fb.z;
+  }
+}
+
+template <bool FORCE_ONLY>
+__global__ void det_nodes_kernel(DeviceMesh m, DetLists det, const double *__restrict__ d0, const double *__restrict__ dn,
+                                 double *__restrict__ out, double *__restrict__ iface, const double *__restrict__ table_row,
+                                 double *__restrict__ hist_row, StepConsts k) {
+  const int64_t node = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (node >= m.n_nodes) return;
+  double f[3] = {0.0, 0.0, 0.0};
+  for (int64_t j = det.contrib_off[node]; j < det.contrib_off[node + 1]; ++j) {  // fixed order: item, then slot
+    const int32_t id = det.contrib[j];
+    const double *v = det.item_force + 15 * (int64_t)(id >> 3) + 3 * (id & 7);
+    f[0] += v[0];
+    f[1] += v[1];
+    f[2] += v[2];
+  }
+  const int32_t tag = m.tag[node];
+  for (int c = 0; c < 3; ++c) {
+    const int64_t i = 3 * node + c;
+    if (FORCE_ONLY) {
+      out[i] = f[c];
+      continue;
+    }
+    if (iface != nullptr && (tag & kTagShared)) iface[3 * (int64_t)(tag >> kTagSlotShift) + c] = f[c];
+    double v = cd_update_dof(f[c], m.fext[i], m.mass[i], d0[i], dn[i], k);
+    if (tag & (1 << c)) v = 0.0;  // d1[Local_Dirichlet] = 0   (Dynamic_solver.py:20)
+    if (table_row != nullptr && (tag & kTagShared)) {  // Online_predictor.py:298,301
+      const int64_t j = 3 * (int64_t)m.slot_sidx[tag >> kTagSlotShift] + c;
+      v = table_row[j];
+      if (hist_row != nullptr) hist_row[j] = v;
+    }
+    out[i] = v;
+  }
+}
+
 // After the all-reduce: shared nodes get the update from the summed force (Dynamic_solver.py:26-32),
 // optional history record (Online_predictor.py:260); slots of shared nodes this rank does not hold
 // are zeroed so that the next all-reduce sees only fresh partial forces.
@@ -965,6 +1047,22 @@ void launch_fused_step(const DeviceMesh &m, int threads, int lds_bytes, hipStrea
                        const StepConsts &k) {
   hipLaunchKernelGGL(fused_step_kernel<false>, dim3(m.n_blocks), dim3(threads), lds_bytes, st, m, d0, dn, d1,
                      iface, table_row, hist_row, k, static_cast<const PeerMap *>(nullptr), 0u);
+}
+
+hipError_t configure_det_kernels(int lds_bytes) {
+  return hipFuncSetAttribute(reinterpret_cast<const void *>(&det_items_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             lds_bytes);
+}
+
+void launch_det_step(const DeviceMesh &m, const DetLists &det, int threads, int lds_bytes, hipStream_t st, const double *d0,
+                     const double *dn, double *out, double *iface, const double *table_row, double *hist_row,
+                     const StepConsts &k, bool force_only) {
+  hipLaunchKernelGGL(det_items_kernel, dim3(m.n_blocks), dim3(threads), lds_bytes, st, m, d0, det.item_force);
+  const unsigned nb = (unsigned)((m.n_nodes + 255) / 256);
+  if (force_only)
+    hipLaunchKernelGGL(det_nodes_kernel<true>, dim3(nb), dim3(256), 0, st, m, det, d0, dn, out, iface, table_row, hist_row, k);
+  else
+    hipLaunchKernelGGL(det_nodes_kernel<false>, dim3(nb), dim3(256), 0, st, m, det, d0, dn, out, iface, table_row, hist_row, k);
 }
 
 void launch_fused_step_peer(const DeviceMesh &m, int threads, int lds_bytes, hipStream_t st, const double *d0,

