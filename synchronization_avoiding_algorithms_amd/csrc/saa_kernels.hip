@@ -145,8 +145,10 @@ __device__ __forceinline__ Rec load_rec(const double *rec, unsigned n) {
   return {{a.x, a.y, b.x}, {b.y, c.x, c.y}};
 }
 // force accumulators: [n_owned][3] doubles (one address computation per node, components at immediate offsets)
+// ALL_OWNED: the caller knows that every vertex of the item is owned (interior items): no test, no branch
+template <bool ALL_OWNED = false>
 __device__ __forceinline__ void flush(double *acc, unsigned n, int n_owned, const Vec3 &f) {
-  if ((int)n < n_owned) {
+  if (ALL_OWNED || (int)n < n_owned) {
     double *a = acc + 3 * n;
     lds_add(a, f.x);
     lds_add(a + 1, f.y);
@@ -171,7 +173,7 @@ struct NoHook {
   __device__ __forceinline__ void operator()() const {}
 };
 // `mid` runs once per call, half-way through the item (after tet A): the resident kernel issues its halo loads there.
-template <int ABLATE, typename Hook = NoHook>
+template <int ABLATE, typename Hook = NoHook, bool ALL_OWNED = false>
 __device__ __forceinline__ void item_forces(const uint2 w, const double *rec, double *acc, int n_owned,
                                             double lam, double mu, int tid, double &sink, unsigned long long *T = nullptr,
                                             Hook mid = Hook()) {
@@ -217,7 +219,7 @@ __device__ __forceinline__ void item_forces(const uint2 w, const double *rec, do
     t0 = stamp();
     T[1] += t0 - t1;  // VALU of tet A
   }
-  if (ABLATE != 1) flush(acc, it.a, n_owned, fa);
+  if (ABLATE != 1) flush<ALL_OWNED>(acc, it.a, n_owned, fa);
   else sink += fa.x + fa.y + fa.z;
   mid();
   if (it.pair) {
@@ -240,16 +242,16 @@ __device__ __forceinline__ void item_forces(const uint2 w, const double *rec, do
       t0 = stamp();
       T[3] += t0 - t1;  // VALU of tet B
     }
-    if (ABLATE != 1) flush(acc, it.b, n_owned, fb);
+    if (ABLATE != 1) flush<ALL_OWNED>(acc, it.b, n_owned, fb);
     else sink += fb.x + fb.y + fb.z;
   }
   if (ABLATE == 1) {
     sink += fp.x + fp.y + fp.z + fq.x + fq.y + fq.z + fr.x + fr.y + fr.z;
     return;
   }
-  flush(acc, it.p, n_owned, fp);
-  flush(acc, it.q, n_owned, fq);
-  flush(acc, it.r, n_owned, fr);
+  flush<ALL_OWNED>(acc, it.p, n_owned, fp);
+  flush<ALL_OWNED>(acc, it.q, n_owned, fq);
+  flush<ALL_OWNED>(acc, it.r, n_owned, fr);
   if (ABLATE == 8) T[4] += stamp() - t0;  // remaining atomics: issue + drain
 }
 
@@ -412,7 +414,7 @@ __global__ void __launch_bounds__(SAA_LB) fused_step_kernel(DeviceMesh m, const 
 #pragma unroll
     for (int j = 0; j < kPreConn; ++j)
       if (tid + j * nt < bd.n_interior)
-        item_forces<ABLATE>(cpre[j], rec, acc, bd.n_owned, m.lambda_, m.mu, tid, sink, T);
+        item_forces<ABLATE, NoHook, true>(cpre[j], rec, acc, bd.n_owned, m.lambda_, m.mu, tid, sink, T);
     // (rare) further interior sweeps, software-pipelined: the next connectivity entry is in flight while
     // the current element computes - a dependent global load per sweep would expose its L2 latency
     if (tid + kPreConn * nt < bd.n_interior) {
@@ -420,7 +422,7 @@ __global__ void __launch_bounds__(SAA_LB) fused_step_kernel(DeviceMesh m, const 
       uint2 cur = conn[tid + kPreConn * nt];
       for (int e = tid + kPreConn * nt; e < bd.n_interior; e += nt) {
         const uint2 nxt = conn[min(e + nt, last)];
-        item_forces<ABLATE>(cur, rec, acc, bd.n_owned, m.lambda_, m.mu, tid, sink, T);
+        item_forces<ABLATE, NoHook, true>(cur, rec, acc, bd.n_owned, m.lambda_, m.mu, tid, sink, T);
         cur = nxt;
       }
     }
@@ -765,6 +767,8 @@ __global__ void __launch_bounds__(SAA_LB) persistent_steps_kernel(DeviceMesh m, 
     //         partly filled round between them -----------------------------------------------------------------
     //         The boundary part starts on a wave boundary (the interior part is padded to a multiple of 64 slots):
     //         the plan packed each list for the LDS banks from ITS first item, in groups of 16 / 32 lanes.
+    //         (the ownership-test-free variant of the interior items, which the fused kernel uses, was measured here
+    //         too: 8.82 against 8.57 us/step - two inlined copies of the item code cost this kernel its last registers)
     for (int p = tid; p < n_post; p += nt) {
       const int e = p < n_ir_pad ? (p < n_ir ? n_pre + p : -1) : bd.n_interior + (p - n_ir_pad);
       if (e >= 0) item_forces<0>(connl[e], rec, acc, bd.n_owned, m.lambda_, m.mu, tid, sink);
