@@ -496,17 +496,19 @@ def main():
                            "note": "algorithmic bytes = SURVEY.md section 8(d) figure for a kernel that re-reads the "
                                    "partition every step; the resident kernel keeps it in LDS and moves less "
                                    "(see traffic)"}
-        # HBM traffic per launch from the committed PMC passes of this same command (rocprofv3 --pmc FETCH_SIZE and
-        # --pmc WRITE_SIZE in separate runs; KiB units; FETCH_SIZE doubled: gfx950 counts 64 B per 128-B request,
-        # MI355X_MICROARCH.md "HBM").  Only for the meshes that were profiled; otherwise null.
+        # HBM traffic per launch from the committed PMC passes of this same kernel and mesh (tools/pmc_collect.sh:
+        # rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes, nothing else enabled; KiB units; FETCH_SIZE
+        # doubled: gfx950 counts 64 B per 128-B request, MI355X_MICROARCH.md "HBM").  Only for the meshes that were
+        # profiled (n = 19 resident, n = 38 fused); otherwise null.
         try:
-            with open(os.path.join(REPO, "profiles", "r01_pmc_summary.json")) as fh:
+            with open(os.path.join(REPO, "profiles", "r02_pmc_summary.json")) as fh:
                 pmc = json.load(fh)
-            key = "resident" if spl > 1 else "q"
-            fetch = pmc[f"{key}_FETCH_SIZE_{n}:FETCH_SIZE"]["mean_per_dispatch"]
-            write = pmc[f"{key}_WRITE_SIZE_{n}:WRITE_SIZE"]["mean_per_dispatch"]
+            key = f"r02_resident{n}" if spl > 1 else f"r02_fused{n}"
+            fetch = pmc[f"{key}:FETCH_SIZE"]["mean_per_dispatch"]
+            write = pmc[f"{key}:WRITE_SIZE"]["mean_per_dispatch"]
             out["roofline"]["traffic"] = (2.0 * fetch + write) * 1024.0
-            out["roofline"]["traffic_source"] = "profiles/r01_pmc_summary.json (rocprofv3 --pmc, separate passes)"
+            out["roofline"]["traffic_source"] = ("profiles/r02_pmc_summary.json (rocprofv3 --pmc, separate passes, "
+                                                 "launches of the same length)")
         except (OSError, KeyError, ValueError):
             pass
         copy_bw = measured_copy_bandwidth()

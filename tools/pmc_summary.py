@@ -22,10 +22,12 @@ def main():
     key, root = args[0], args[1]
     sub = args[2] if len(args) > 2 else "step"
     grid = None
-    for a in sys.argv[1:]:
+    full_only = "--full-only" in sys.argv[1:]  # keep only dispatches within 10 % of the largest value of their counter
+    for a in sys.argv[1:]:                     # (drops the resident kernel's census launch and short warm-up launches)
         if a.startswith("--grid="):
             grid = int(a.split("=", 1)[1])
     acc = {}
+    rows = []
     for path in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
         with open(path, newline="") as fh:
             for row in csv.DictReader(fh):
@@ -33,9 +35,16 @@ def main():
                     continue
                 if grid is not None and int(row["Grid_Size"]) != grid:
                     continue
-                d = acc.setdefault(row["Counter_Name"], {"sum": 0.0, "n": 0, "kernel": row["Kernel_Name"][:80]})
-                d["sum"] += float(row["Counter_Value"])
-                d["n"] += 1
+                rows.append((row["Counter_Name"], float(row["Counter_Value"]), row["Kernel_Name"][:80]))
+    top = {}
+    for name, value, _ in rows:
+        top[name] = max(top.get(name, 0.0), value)
+    for name, value, kernel in rows:
+        if full_only and value < 0.9 * top[name]:
+            continue
+        d = acc.setdefault(name, {"sum": 0.0, "n": 0, "kernel": kernel})
+        d["sum"] += value
+        d["n"] += 1
     out_path = os.path.join(REPO, "profiles", "r02_pmc_summary.json")
     for a in sys.argv[1:]:
         if a.startswith("--out="):
