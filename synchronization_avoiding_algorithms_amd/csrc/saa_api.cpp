@@ -427,6 +427,7 @@ int try_persistent_steps(saa_solver *s, int32_t nsteps, const double *table_dev,
     a.timeout_ticks = static_cast<int64_t>(timeout_s * 1e8);
     a.peer = peer ? s->px_map.p : nullptr;
     a.peer_seq_base = s->peer_seq;
+    a.consts = s->consts;
     a.traj = s->rec_traj;
     a.new_to_old = s->new_to_old.p;
     a.traj_cols = s->rec_cols;

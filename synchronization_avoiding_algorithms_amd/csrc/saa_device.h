@@ -120,6 +120,8 @@ struct PersistArgs {
   const int32_t *new_to_old;
   int64_t traj_cols, step_index0;  // step index of the first step of this launch
   int32_t save_every;
+  StepConsts consts;        // the PEER variant reads the step constants from here once per step (update phase) instead
+                            // of holding the by-value copy in scalar registers through the item loops
   int32_t *census;          // non-null: census launch - every workgroup checks in here and waits for the full count
 };
 

@@ -698,7 +698,8 @@ __global__ void __launch_bounds__(SAA_LB) persistent_steps_kernel(DeviceMesh m, 
 #define PSTAMP(j)
 #endif
   for (int s = 0; s < a.nsteps; ++s) {
-    k.ramp = a.ramp_on ? (tn <= 1 ? tn : 1.0) : 1.0;  // commons.py:7-11 at the time of d^n
+    const double ramp_now = a.ramp_on ? (tn <= 1 ? tn : 1.0) : 1.0;  // commons.py:7-11 at the time of d^n
+    if (!PEER) k.ramp = ramp_now;
     // Opaque copy of the thread index for the halo and update phases: whatever is derived from it is recomputed
     // every step.  Derived from `tid` the compiler hoists those per-thread constants (indices, addresses) out of
     // the step loop, keeps them alive through the item loops and spills.
@@ -794,6 +795,12 @@ __global__ void __launch_bounds__(SAA_LB) persistent_steps_kernel(DeviceMesh m, 
         traj_col = ap->traj + idx / every;
         traj_ld = ap->traj_cols;
       }
+    }
+    if (PEER) {  // step constants from the argument block, not from registers held since the launch
+      const StepConsts *kp = &ap->consts;
+      asm volatile("" : "+s"(kp));
+      k = *kp;
+      k.ramp = ramp_now;
     }
     auto commit = [&](int i, int n, int c, double u, double v) {
       if (keep) gnext[base + i] = v;
