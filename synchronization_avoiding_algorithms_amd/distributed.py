@@ -116,12 +116,12 @@ class PartitionedSolver:
             handle, order = self.solver.peer_export(self.world)
         except Exception:  # noqa: BLE001
             ok = 0
-        info = (ok, handle, self.device_ordinal, slots, order)
+        info = (ok, handle, self.device_ordinal, slots, order, self._physical_device_id())
         box = [None] * self.world
         dist.all_gather_object(box, info, group=self.group)
         import os
 
-        if (len({b[2] for b in box}) < self.world and hasattr(self.solver, "set_resident_kernel")
+        if (len({b[5] for b in box}) < self.world and hasattr(self.solver, "set_resident_kernel")
                 and os.environ.get("SAA_FORCE_RESIDENT") != "1"):  # (the override is for tests of that very path)
             # ranks sharing one GPU (rehearsals, the one-GPU test box): a resident kernel waiting for another
             # process' kernel only advances by time-slicing - keep one launch per step
@@ -140,6 +140,24 @@ class PartitionedSolver:
         except Exception:  # noqa: BLE001
             ok = 0
         return self._agree(ok)
+
+    def _physical_device_id(self):
+        """Something that tells two physical GPUs apart even when a launcher shows every rank its own GPU as ordinal 0
+        (HIP_VISIBLE_DEVICES): UUID, else PCI address, else host name + ordinal."""
+        import socket
+
+        import torch
+
+        try:
+            p = torch.cuda.get_device_properties(self.device_ordinal)
+            for name in ("uuid", "pci_bus_id"):
+                v = getattr(p, name, None)
+                if v is not None and str(v) not in ("", "None"):
+                    extra = (getattr(p, "pci_domain_id", 0), getattr(p, "pci_device_id", 0)) if name == "pci_bus_id" else ()
+                    return (socket.gethostname(), name, str(v), *extra)
+        except Exception:  # noqa: BLE001
+            pass
+        return (socket.gethostname(), "ordinal", self.device_ordinal)
 
     def _init_native_exchange(self) -> bool:
         """Join an RCCL communicator owned by the C++ side (``saa_comm_init``); on any failure keep the
