@@ -70,3 +70,30 @@ def test_graph_captured_training_step_matches_eager_training(tmp_path, monkeypat
     assert a.keys() == b.keys()
     for k in a:
         assert torch.allclose(a[k], b[k], rtol=0, atol=5e-3), k
+
+
+def test_training_from_a_history_tensor_matches_the_file_path(tmp_path):
+    """``windows_from_history`` / ``train_on_history`` (what bench.py's sync-avoiding leg uses: the shared-dof history a
+    synchronised run left in memory, ``d_sol_shared`` layout) give the windows, scaling constants and - with the same
+    seed - the model of the file-based ``train_rank_model`` (Shared_extraction.py layout, the transpose)."""
+    traj = _fake_shared_trajectory(n_in=6, n_steps=900)          # (in, steps) as Shared_extraction.py stores it
+    hist = torch.from_numpy(traj.T.copy())                        # (steps, in) as Online_predictor.py:260 fills it
+    X, Y = tr.windowed_dataset(traj, 10, 4, 3, 1.0)
+    Xh, Yh = tr.windows_from_history(hist, 10, 4, 3, 1.0)
+    assert torch.equal(X, Xh) and torch.equal(Y, Yh)
+    model, smax, smin, tl, vl = tr.train_on_history(hist, 10, 4, 3, cut_off=1.0, seed=3, hidden_size=8, num_epochs=5,
+                                                    learning_rate=5e-3)
+    assert (smax, smin) == pr.scaling_constants(traj, 10, 4, 3, 1.0)
+    assert len(tl) == len(vl) == 5 and tl[-1] < tl[0] and not model.training
+    out = str(tmp_path)
+    rio.save_int_list(os.path.join(out, drivers.PATHS["shared"].format(r=0)), [3, 9])
+    rio.save_displacement(os.path.join(out, drivers.PATHS["shared_traj"].format(r=0)), traj, compress=False)
+    path, tl2, _ = tr.train_rank_model(out, 0, device="cpu", hidden_size=8, filter_size=10, n_past=4, n_future=3,
+                                       cut_off=1.0, num_epochs=5, learning_rate=5e-3, seed=3)
+    assert np.allclose(tl, tl2, rtol=1e-6)
+    saved = torch.load(path, weights_only=True)
+    for k, v in model.state_dict().items():
+        assert torch.allclose(v, saved[k], atol=1e-6), k
+    # the time bound ends training early
+    _, _, _, tl3, _ = tr.train_on_history(hist, 10, 4, 3, seed=3, hidden_size=8, num_epochs=10000, max_seconds=0.5)
+    assert 1 <= len(tl3) < 10000
