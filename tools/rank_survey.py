@@ -1,33 +1,42 @@
 #!/usr/bin/env python3
 """Diagnostic: every rank's partition of the N = 2, 4, 8 bench configurations on ONE GPU - plan, whether the
-resident kernel holds it, and its exchange-free step time (the slowest rank paces a synchronised run).
+resident kernel holds it, its exchange-free step time and its step time through the peer exchange with loop-back
+neighbours (the slowest rank paces a synchronised run).
 
-    python tools/rank_survey.py
+    python tools/rank_survey.py [N ...]
 """
-import os, sys, time
+import os
+import sys
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np
-from bench import N_FOR_GPUS, E, NU, RHO, FZ, ALPHA, GAMMA
-import synchronization_avoiding_algorithms_amd as saa
-from synchronization_avoiding_algorithms_amd import fem_setup as fs
-from synchronization_avoiding_algorithms_amd.mesh import clamp_nodes, slab_partition, structured_beam
-for world in (2, 4, 8):
-    n = N_FOR_GPUS[world]
-    mesh = structured_beam(n)
-    epart = slab_partition(mesh, world)
-    layouts, gshared = fs.build_layouts(mesh.tets, epart, world, len(mesh.points), clamp_nodes(mesh))
-    lumped, fpre = fs.lumped_mass_and_load(mesh.points, mesh.tets, RHO, FZ)
-    dt = fs.cfl_dt(mesh.points, mesh.tets, E, NU, RHO, GAMMA)
-    lmd, mu = fs.lame(E, NU)
+import torch  # noqa: E402
+
+from bench import N_FOR_GPUS, build_rank_solver  # noqa: E402
+from synchronization_avoiding_algorithms_amd.mesh import structured_beam  # noqa: E402
+
+
+def timed(fn, steps):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    fn(steps)
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / steps * 1e3
+
+
+for world in ([int(a) for a in sys.argv[1:]] or (2, 4, 8)):
+    mesh = structured_beam(N_FOR_GPUS[world])
     for r in range(world):
-        lay = layouts[r]
-        sol = saa.HipExplicitSolver(mesh.points[lay.nodes], lay.cells_local, lumped[lay.local_dof], fpre[lay.local_dof],
-                                    lay.dirichlet_dofs, lmd, mu, dt, ALPHA, shared_local=lay.shared_local,
-                                    shared_slots=lay.shared_slots, n_global_shared=len(gshared))
+        sol, lay, _, _ = build_rank_solver(mesh, world, r, 0)
         st, ri = sol.plan_stats(), sol.resident_kernel_info()
-        sol.step(200)
-        us = sol.time_steps(2000) / 2000 * 1e3
+        sol.step(1000)
+        plain = timed(sol.step, 3000)
+        sol.peer_attach_loopback(2)
+        sol.step_peer(1000)
+        peer = timed(sol.step_peer, 3000)
+        sol.synchronize()
         print(f"N={world} rank {r}: tets {len(lay.cells_local)} nodes {len(lay.nodes)} shared {len(lay.shared_local)} "
-              f"blocks {st['n_blocks']} max_owned {st['max_owned']} max_local {st['max_local']} resident {ri['capable']} "
-              f"lds {ri['lds_bytes']}  exchange-free step {us:.2f} us", flush=True)
+              f"blocks {st['n_blocks']} max_owned {st['max_owned']} max_local {st['max_local']} conflict "
+              f"{st['lds_conflict_factor']:.3f} resident {ri['capable']} lds {ri['lds_bytes']}  step {plain:.2f} us, "
+              f"with peer exchange (loop-back) {peer:.2f} us", flush=True)
         sol.close()
