@@ -59,6 +59,10 @@ def main():
     barrier()
     t1 = time.time()
     drivers.shared_extraction(args.out, rank)
+    if world == 1:  # one partition: no shared nodes, nothing to predict (the reference's example runs on >= 2 ranks)
+        print(f"[rank 0] steps {args.steps}: data_prepare {t1 - t0:.1f} s; a single partition has no shared nodes - run "
+              "with --nproc-per-node 2 (add --same-device --backend gloo on a one-GPU machine) for the sync-avoiding part")
+        return
     path, tl, vl = training.train_rank_model(args.out, rank, device=f"cuda:{local}", hidden_size=args.hidden_size,
                                              filter_size=args.filter_size, num_epochs=args.epochs, seed=rank, verbose=True)
     barrier()

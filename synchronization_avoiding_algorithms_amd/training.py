@@ -257,6 +257,8 @@ def train_rank_model(out_dir=".", rank=0, device=None, batch_size=10, learning_r
         gen = torch.Generator().manual_seed(seed)
     shared = rio.load_int_list(os.path.join(out_dir, PATHS["shared"].format(r=rank)))
     traj = rio.load_displacement(os.path.join(out_dir, PATHS["shared_traj"].format(r=rank)))
+    if len(shared) == 0:
+        raise ValueError(f"rank {rank} has no shared nodes: nothing to train (a one-partition run)")
     if traj.shape[0] != 3 * len(shared):
         raise ValueError("shared-dof trajectory and shared-node list disagree")
     X, Y = windowed_dataset(traj, filter_size, n_past, n_future, cut_off, device)
