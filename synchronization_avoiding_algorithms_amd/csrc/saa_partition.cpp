@@ -74,10 +74,16 @@ class Bisector {
     const int32_t far1 = farthest(elems, far0);
     int64_t best_cut = -1;
     std::vector<uint8_t> best;
-    for (int trial = 0; trial < 2; ++trial) {
-      // growing side 0 from far0, or side 1 from far1 (mirror image: then side 0 is what is left over)
-      grow(elems, trial == 0 ? far0 : far1, trial == 0 ? target_left : static_cast<int64_t>(elems.size()) - target_left,
-           trial == 0 ? 0 : 1);
+    for (int trial = 0; trial < 3; ++trial) {
+      // trial 0 / 1: side 0 grown from far0, or side 1 from far1 (mirror image: side 0 is what is left over);
+      // trial 2: both ends at once - the elements in the order of (distance to far0) - (distance to far1), the first
+      // target_left of them on side 0: the front is the equidistance surface of the two ends, a cross-section of an
+      // elongated part where a one-sided growth gives a spherical cap
+      if (trial < 2)
+        grow(elems, trial == 0 ? far0 : far1,
+             trial == 0 ? target_left : static_cast<int64_t>(elems.size()) - target_left, trial == 0 ? 0 : 1);
+      else
+        split_by_distance_difference(elems, far0, far1, target_left);
       const int64_t cut = refine(elems, target_left);
       if (best_cut < 0 || cut < best_cut) {
         best_cut = cut;
@@ -111,6 +117,43 @@ class Bisector {
     }
     (void)elems;
     return queue_.back();
+  }
+
+  // breadth-first distances from `start` inside the subset into dist (unreached elements keep `far`)
+  void distances(const std::vector<int32_t> &elems, int32_t start, std::vector<int32_t> &dist, int32_t far) {
+    for (int32_t e : elems) dist[e] = far;
+    queue_.clear();
+    queue_.push_back(start);
+    dist[start] = 0;
+    for (size_t h = 0; h < queue_.size(); ++h) {
+      const int32_t e = queue_[h];
+      for (int k = 0; k < 4; ++k) {
+        const int32_t f = g_.nb(e)[k];
+        if (in(f) && dist[f] == far) {
+          dist[f] = dist[e] + 1;
+          queue_.push_back(f);
+        }
+      }
+    }
+  }
+
+  void split_by_distance_difference(const std::vector<int32_t> &elems, int32_t a, int32_t b, int64_t target_left) {
+    if (d0_.empty()) {
+      d0_.assign(g_.n, 0);
+      d1_.assign(g_.n, 0);
+    }
+    const int32_t far = g_.n + 1;
+    distances(elems, a, d0_, far);
+    distances(elems, b, d1_, far);
+    order_.assign(elems.begin(), elems.end());
+    // ties (a whole layer of equal difference): by the distance to `a`, then by id - keeps the split layer compact
+    std::sort(order_.begin(), order_.end(), [&](int32_t x, int32_t y) {
+      const int32_t kx = d0_[x] - d1_[x], ky = d0_[y] - d1_[y];
+      if (kx != ky) return kx < ky;
+      if (d0_[x] != d0_[y]) return d0_[x] < d0_[y];
+      return x < y;
+    });
+    for (size_t i = 0; i < order_.size(); ++i) side_[order_[i]] = static_cast<int64_t>(i) < target_left ? 0 : 1;
   }
 
   // graph growing: the region (side `s`) is the `target` elements nearest to the seed in the dual graph (breadth-first
@@ -236,7 +279,7 @@ class Bisector {
   std::vector<int32_t> &part_;
   std::vector<uint8_t> side_;
   std::vector<int32_t> mark_, gain_, lock_;
-  std::vector<int32_t> queue_, moves_;
+  std::vector<int32_t> queue_, moves_, d0_, d1_, order_;
   std::vector<int32_t> fm_[2][9];
   int32_t stamp_ = 0, tag_ = 0;
 };
