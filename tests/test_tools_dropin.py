@@ -110,3 +110,32 @@ def test_shape_functions_and_quadrature_match_the_reference():
         S.Shape_Function(2, [0.1, 0.1, 0.1])
     with pytest.raises(NotImplementedError):
         Q.Gauss_Legendre(4)
+
+
+def test_every_tools_name_the_reference_drivers_use_exists():
+    """the reference's four driver scripts run against this package's ``Tools``.  Reads the
+    reference's sources as text (build container only; skipped where /root/reference does not exist)."""
+    import ast
+    import importlib
+    import os
+
+    import pytest
+
+    ref = "/root/reference"
+    if not os.path.isdir(os.path.join(ref, "Tools")):
+        pytest.skip("the reference is not present on this machine")
+    defined = {}
+    for f in os.listdir(os.path.join(ref, "Tools")):
+        if f.endswith(".py"):
+            with open(os.path.join(ref, "Tools", f)) as fh:
+                for node in ast.parse(fh.read()).body:
+                    if isinstance(node, (ast.FunctionDef, ast.ClassDef)):
+                        defined.setdefault(node.name, []).append(f[:-3])
+    used = set()
+    for drv in ("Data_prepare.py", "Online_predictor.py", "Shared_extraction.py", "Model_training.py"):
+        with open(os.path.join(ref, drv)) as fh:
+            used |= {n.id for n in ast.walk(ast.parse(fh.read())) if isinstance(n, ast.Name) and n.id in defined}
+    assert len(used) >= 20
+    for name in sorted(used):
+        mods = [importlib.import_module(f"synchronization_avoiding_algorithms_amd.Tools.{m}") for m in defined[name]]
+        assert any(hasattr(m, name) for m in mods), name
