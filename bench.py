@@ -316,7 +316,7 @@ def main():
     ap.add_argument("--sa-filter", type=int, default=150, help="sync-avoiding leg: filter_size n_s (Online_predictor.py:59)")
     ap.add_argument("--sa-truth-steps", type=int, default=30000,
                     help="sync-avoiding leg: synchronised steps recorded as training data")
-    ap.add_argument("--sa-train-seconds", type=float, default=40.0, help="sync-avoiding leg: training time bound per rank")
+    ap.add_argument("--sa-train-seconds", type=float, default=60.0, help="sync-avoiding leg: training time bound per rank")
     ap.add_argument("--no-rccl-leg", action="store_true",
                     help="N > 1: skip the extra measurement with the RCCL all-reduce when the peer exchange is in use")
     ap.add_argument("--torch-exchange", action="store_true",
