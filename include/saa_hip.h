@@ -80,7 +80,7 @@ typedef struct saa_plan_stats {
 } saa_plan_stats;
 
 const char *saa_last_error(void);
-/* Library / ABI version; bumps when this header changes (2: peer exchange and resident-kernel entry points; 3: loop-back attach; 4: partitioner and set-up kernels; 5: deterministic mode; 6: saa_multistep_kernel_info). */
+/* Library / ABI version; bumps when this header changes (2: peer exchange and resident-kernel entry points; 3: loop-back attach; 4: partitioner and set-up kernels; 5: deterministic mode). */
 int32_t saa_abi_version(void);
 
 /* Element partition, one part per rank / GPU: the role of `_, epart = part_mesh_kway(size, eptr, eind)` (mgmetis /
@@ -233,13 +233,6 @@ int saa_halo_scatter(saa_solver *s, const double *row_dev);
  * DESIGN.md section 4) and how much LDS a workgroup of it holds.  capable = 0: the plan does not fit or the device
  * cannot keep all workgroups co-resident; every step is then one launch of the fused kernel. */
 int saa_resident_kernel_info(const saa_solver *s, int32_t *capable, int32_t *lds_bytes, int32_t *steps_per_launch);
-/* How plain multi-step calls (saa_step, >= 8 steps) are executed on this handle: kind 0 = one launch of the fused
- * kernel per step; 1 = the resident kernel above; 2 = the cycling kernel - for partitions with more plan blocks than
- * co-resident workgroups (8M tets on one GPU): one launch per <= 1000 steps, every workgroup walking through its
- * share of the blocks step after step, blocks of step s+1 starting as soon as their neighbours have finished step s
- * (no launch boundary, no grid-wide barrier between steps).  workgroups = grid of that kernel (0 for kind 0).
- * (No reference counterpart: how the loop of Data_prepare.py:223-240 is scheduled on the device.) */
-int saa_multistep_kernel_info(const saa_solver *s, int32_t *kind, int32_t *workgroups);
 /* enable = 0: keep this handle on one launch per step (for callers that know the device is shared with other
  * processes: workgroups of a resident kernel that wait for another process' kernel only advance by time-slicing). */
 int saa_set_resident_kernel(saa_solver *s, int32_t enable);

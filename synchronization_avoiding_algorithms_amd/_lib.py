@@ -20,7 +20,7 @@ HEADER = os.path.join(os.path.dirname(_HERE), "include", "saa_hip.h")
 SOURCES = ["saa_plan.cpp", "saa_partition.cpp", "saa_kernels.hip", "saa_setup.hip", "saa_api.cpp"]
 HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics", "-ldl"]
 
-ABI_VERSION = 6  # what saa_abi_version() of a matching library returns (include/saa_hip.h)
+ABI_VERSION = 5  # what saa_abi_version() of a matching library returns (include/saa_hip.h)
 SAA_OK, SAA_E_ARG, SAA_E_HIP, SAA_E_STATE, SAA_E_CAPACITY = 0, -1, -2, -3, -4
 
 
@@ -93,7 +93,6 @@ SIGNATURES = {
     "saa_step_synced": (C.c_int, [_H, C.c_int32, C.c_void_p, C.c_int64]),
     "saa_resident_kernel_info": (C.c_int, [_H, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "saa_set_recorder": (C.c_int, [_H, C.c_void_p, C.c_int64, C.c_int32, C.c_int64]),
-    "saa_multistep_kernel_info": (C.c_int, [_H, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "saa_set_resident_kernel": (C.c_int, [_H, C.c_int32]),
     "saa_set_deterministic": (C.c_int, [_H, C.c_int32]),
     "saa_peer_export": (C.c_int, [_H, C.c_int32, C.POINTER(C.c_uint8), C.POINTER(C.c_int32)]),

@@ -4,7 +4,6 @@
 #include <dlfcn.h>
 
 #include <algorithm>
-#include <numeric>
 #include <climits>
 #include <cmath>
 #include <cstdlib>
@@ -126,11 +125,6 @@ struct saa_solver {
   DevBuf<saa::PeerEntry> ps_entries;  // 2 x 3*n_nodes stamped displacements
   DevBuf<saa::PersistArgs> ps_args;   // argument block of the launch in flight
   int32_t ps_lds = 0, ps_max_items = 0, ps_steps = 0;
-  // cycling multi-step kernel (saa_device.h: CycleArgs): partitions with several plan blocks per workgroup slot
-  DevBuf<int32_t> cy_flags, cy_halo_blk, cy_queue, cy_order;
-  DevBuf<saa::CycleArgs> cy_args;
-  int32_t cy_grid = 0, cy_steps = 0;
-  bool cy_capable = false;
   bool ps_capable = false;  // plan fits LDS and all workgroups can be co-resident
   bool ps_enabled = true;   // saa_set_resident_kernel
   // trajectory recorder (saa_set_recorder)
@@ -181,7 +175,6 @@ struct saa_solver {
     for (auto &b : dbuf) b.release();
     for (auto &b : scratch) b.release();
     ps_entries.release(); ps_err.release(); ps_args.release();
-    cy_flags.release(); cy_halo_blk.release(); cy_queue.release(); cy_order.release(); cy_args.release();
     det_force.release(); det_off.release(); det_contrib.release();
     for (void *q : peer_open) (void)hipIpcCloseMemHandle(q);
     peer_open.clear();
@@ -327,7 +320,7 @@ int check_peer_error(saa_solver *s) {
 constexpr int32_t kPersistMinSteps = 8;
 
 int check_persist_error(saa_solver *s) {
-  if (!s->ps_capable && !s->cy_capable) return SAA_OK;
+  if (!s->ps_capable) return SAA_OK;
   int32_t e = 0;
   HIP_TRY(hipMemcpy(&e, s->ps_err.p, sizeof(e), hipMemcpyDeviceToHost));
   if (e != 0) return fail(SAA_E_STATE, "resident step kernel: timed out waiting for a neighbouring workgroup");
@@ -457,164 +450,6 @@ int try_persistent_steps(saa_solver *s, int32_t nsteps, const double *table_dev,
   return SAA_OK;
 }
 
-// The cycling kernel serves plans the resident kernel cannot hold (more plan blocks than co-resident workgroups): the
-// grid is the largest co-resident one that divides the block count evenly over the 8 XCDs' runs, proved by a census launch.
-// Order in which the queue of every XCD hands out the blocks of its run within a step.  A block of step s waits for its
-// neighbours' step s-1; with all queues advancing at the same rate that never stalls if neighbouring blocks sit at
-// similar positions of their queues (within ~3/4 of a step).  The plan order (recursive bisection) puts blocks that
-// face each other across two runs at opposite ends.  Instead every queue sweeps its run along one axis - the one along
-// which the runs' extents coincide best - measured inside the run's own bounding box and mirrored for runs in the upper
-// half of the domain, so that blocks on either side of any boundary between two runs carry the same sweep coordinate.
-std::vector<int32_t> cycling_order(const saa::Plan &plan, const std::vector<double> &xyz) {
-  const int32_t nb = static_cast<int32_t>(plan.blocks.size());
-  std::vector<double> cen(3 * static_cast<size_t>(nb), 0.0);
-  for (int32_t b = 0; b < nb; ++b) {
-    const saa::BlockDesc &d = plan.blocks[b];
-    for (int32_t i = d.node_start; i < d.node_start + d.n_owned; ++i)
-      for (int c = 0; c < 3; ++c) cen[3 * b + c] += xyz[3 * static_cast<size_t>(i) + c];
-    for (int c = 0; c < 3; ++c) cen[3 * b + c] /= std::max(1, d.n_owned);
-  }
-  const int per = nb >> 3, rem = nb & 7;
-  int32_t run0[9];
-  for (int x = 0; x <= 8; ++x) run0[x] = x * per + std::min(x, rem);
-  double lo[8][3], hi[8][3], glo[3], ghi[3];
-  for (int c = 0; c < 3; ++c) glo[c] = 1e300, ghi[c] = -1e300;
-  for (int x = 0; x < 8; ++x)
-    for (int c = 0; c < 3; ++c) {
-      lo[x][c] = 1e300, hi[x][c] = -1e300;
-      for (int32_t b = run0[x]; b < run0[x + 1]; ++b) {
-        lo[x][c] = std::min(lo[x][c], cen[3 * b + c]);
-        hi[x][c] = std::max(hi[x][c], cen[3 * b + c]);
-      }
-      glo[c] = std::min(glo[c], lo[x][c]);
-      ghi[c] = std::max(ghi[c], hi[x][c]);
-    }
-  int axis = 0;
-  double best = -1.0;
-  for (int c = 0; c < 3; ++c) {  // share of the domain's extent along c that every run covers
-    double common_lo = -1e300, common_hi = 1e300;
-    for (int x = 0; x < 8; ++x)
-      if (run0[x + 1] > run0[x]) common_lo = std::max(common_lo, lo[x][c]), common_hi = std::min(common_hi, hi[x][c]);
-    const double ext = ghi[c] - glo[c];
-    const double score = ext > 0 ? std::max(0.0, common_hi - common_lo) / ext : 0.0;
-    if (score > best) best = score, axis = c;
-  }
-  std::vector<int32_t> order(nb);
-  std::iota(order.begin(), order.end(), 0);
-  if (std::getenv("SAA_CYCLING_PLAN_ORDER")) return order;  // experiments: the plan's own order
-  std::vector<double> tau(nb, 0.0);
-  for (int x = 0; x < 8; ++x) {
-    const double ext = hi[x][axis] - lo[x][axis], mid = 0.5 * (glo[axis] + ghi[axis]);
-    const bool mirrored = 0.5 * (lo[x][axis] + hi[x][axis]) > mid + 1e-9 * (ghi[axis] - glo[axis]);
-    for (int32_t b = run0[x]; b < run0[x + 1]; ++b) {
-      const double t = ext > 0 ? (cen[3 * b + axis] - lo[x][axis]) / ext : 0.0;
-      tau[b] = mirrored ? 1.0 - t : t;
-    }
-    std::stable_sort(order.begin() + run0[x], order.begin() + run0[x + 1], [&](int32_t a, int32_t b) { return tau[a] < tau[b]; });
-  }
-  return order;
-}
-
-void setup_cycling(saa_solver *s, const std::vector<double> &xyz) {
-  s->cy_capable = false;
-  if (s->ps_capable) return;
-  if (const char *env = std::getenv("SAA_NO_CYCLING"))
-    if (env[0] == '1') return;
-  const saa::Plan &plan = s->plan;
-  const int32_t nb = static_cast<int32_t>(plan.blocks.size());
-  int grid = saa::cycling_max_blocks(s->device, s->threads, s->lds_bytes);
-  if (const char *env = std::getenv("SAA_CYCLING_GRID")) grid = std::min(grid, std::atoi(env));  // tests
-  grid -= grid % 8;  // the same number of workgroups on every XCD
-  if (grid < 8 || nb < 2 * grid) return;
-  std::vector<int32_t> halo_blk(plan.halo_ids.size() + 1, 0);
-  {
-    std::vector<int32_t> starts(nb);
-    for (int32_t b = 0; b < nb; ++b) starts[b] = plan.blocks[b].node_start;
-    for (size_t i = 0; i < plan.halo_ids.size(); ++i)
-      halo_blk[i] = static_cast<int32_t>(std::upper_bound(starts.begin(), starts.end(), plan.halo_ids[i]) - starts.begin()) - 1;
-  }
-  if (!s->ps_err.p && s->ps_err.upload(std::vector<int32_t>(1, 0)) != hipSuccess) return;
-  if (s->cy_halo_blk.upload(halo_blk) != hipSuccess || s->cy_flags.upload(std::vector<int32_t>(nb, 0)) != hipSuccess ||
-      s->cy_queue.upload(std::vector<int32_t>(8, 0)) != hipSuccess || s->cy_args.alloc(1) != hipSuccess ||
-      s->cy_order.upload(cycling_order(plan, xyz)) != hipSuccess) {
-    (void)hipGetLastError();
-    return;
-  }
-  DevBuf<int32_t> counter;
-  bool ok = counter.upload(std::vector<int32_t>(1, 0)) == hipSuccess;
-  saa::CycleArgs a{};
-  a.census = counter.p;
-  a.err = s->ps_err.p;
-  a.timeout_ticks = 5000000;  // 50 ms of the 100 MHz wall clock
-  ok = ok && saa::launch_cycling_steps(s->mesh, grid, s->threads, s->lds_bytes, s->stream, s->cy_args.p, a) == hipSuccess;
-  ok = ok && hipStreamSynchronize(s->stream) == hipSuccess;
-  int32_t e = 1, seen = 0;
-  ok = ok && hipMemcpy(&e, s->ps_err.p, sizeof(e), hipMemcpyDeviceToHost) == hipSuccess &&
-       hipMemcpy(&seen, counter.p, sizeof(seen), hipMemcpyDeviceToHost) == hipSuccess;
-  counter.release();
-  if (!ok || e != 0 || seen != grid) {
-    (void)hipGetLastError();
-    const int32_t zero = 0;
-    (void)hipMemcpy(s->ps_err.p, &zero, sizeof(zero), hipMemcpyHostToDevice);
-    return;
-  }
-  s->cy_grid = grid;
-  s->cy_steps = 0;
-  s->cy_capable = true;
-}
-
-#ifdef SAA_DIAGNOSTICS
-long long *g_cycling_prof = nullptr;  // saa_debug_cycling_profile
-#endif
-// Plain steps through the cycling kernel (launches of at most kPersistChunk steps); *n_done as in try_persistent_steps.
-int try_cycling_steps(saa_solver *s, int32_t nsteps, int32_t *n_done) {
-  if (*n_done >= nsteps || s->det || !s->cy_capable || !s->ps_enabled || nsteps - *n_done < kPersistMinSteps || s->rec_traj)
-    return SAA_OK;
-  double timeout_s = 30.0;
-  if (const char *env = std::getenv("SAA_PEER_TIMEOUT_S")) timeout_s = std::max(1e-7, std::atof(env));
-  while (*n_done < nsteps) {
-    int32_t n = std::min(kPersistChunk, nsteps - *n_done);
-    if (static_cast<uint32_t>(s->cy_steps) > 0x7fff0000u) {  // progress counters about to wrap: start over
-      HIP_TRY(hipMemsetAsync(s->cy_flags.p, 0, s->cy_flags.n * sizeof(int32_t), s->stream));
-      s->cy_steps = 0;
-    }
-    saa::CycleArgs a{};
-    a.buf[0] = s->dbuf[s->i0].p;
-    a.buf[1] = s->dbuf[s->i1].p;
-    a.buf[2] = s->dbuf[s->in_].p;
-    a.nsteps = n;
-    a.queue = s->cy_queue.p;
-    a.order = s->cy_order.p;
-    a.flags = s->cy_flags.p;
-    a.flag_base = s->cy_steps;
-    a.halo_blk = s->cy_halo_blk.p;
-    a.tn0 = s->tn;
-    a.ramp_on = s->ramp;
-    a.err = s->ps_err.p;
-    a.timeout_ticks = static_cast<int64_t>(timeout_s * 1e8);
-    a.consts = s->consts;
-#ifdef SAA_DIAGNOSTICS
-    a.prof = g_cycling_prof;
-#endif
-    if (saa::launch_cycling_steps(s->mesh, s->cy_grid, s->threads, s->lds_bytes, s->stream, s->cy_args.p, a) != hipSuccess) {
-      (void)hipGetLastError();
-      s->cy_capable = false;
-      return SAA_OK;
-    }
-    s->cy_steps += n;
-    for (int32_t k = 0; k < n; ++k) {
-      const int old_n = s->in_;
-      s->in_ = s->i0;
-      s->i0 = s->i1;
-      s->i1 = old_n;
-      s->tn = s->tn + s->consts.dt;  // the kernel advanced its copy the same way
-    }
-    s->rec_index += n;
-    *n_done += n;
-  }
-  return SAA_OK;
-}
-
 // one step kernel (or pair of kernels in deterministic mode) from d^n, d^(n-1) into d^(n+1)
 void launch_step(saa_solver *s, double *iface, const double *table_row, double *hist_row) {
   if (s->det)
@@ -645,7 +480,7 @@ extern "C" {
 
 const char *saa_last_error(void) { return g_last_error.c_str(); }
 
-int32_t saa_abi_version(void) { return 6; }  // 4: saa_part_mesh_kway, saa_setup_fields; 5: saa_set_deterministic; 6: cycling kernel info
+int32_t saa_abi_version(void) { return 5; }  // 4: saa_part_mesh_kway, saa_setup_fields; 5: saa_set_deterministic
 
 int saa_plan_host_stats(int32_t n_nodes, int32_t n_elems, const double *xyz, const int32_t *tets,
                         int32_t block_nodes, saa_plan_stats *out) {
@@ -856,7 +691,6 @@ int saa_create(const saa_problem *pb, saa_solver **out) {
   s->consts.half_alpha = 0.5 * pb->alpha;
   s->tn = 0.0;
   setup_persistent(s);
-  setup_cycling(s, xyz);
   *out = s;
   return SAA_OK;
 }
@@ -973,7 +807,6 @@ int saa_step(saa_solver *s, int32_t nsteps) {
   HIP_TRY(hipSetDevice(s->device));
   int32_t k0 = 0;
   if (int rc = try_persistent_steps(s, nsteps, nullptr, 0, nullptr, 0, &k0)) return rc;
-  if (int rc = try_cycling_steps(s, nsteps, &k0)) return rc;
   for (int32_t k = k0; k < nsteps; ++k) {
     s->set_ramp();
     launch_step(s, nullptr, nullptr, nullptr);
@@ -1389,15 +1222,6 @@ int saa_halo_scatter(saa_solver *s, const double *row_dev) {
   return check_launch();
 }
 
-int saa_multistep_kernel_info(const saa_solver *s, int32_t *kind, int32_t *workgroups) {
-  if (!s) return fail(SAA_E_ARG, "saa_multistep_kernel_info: null handle");
-  const bool on = s->ps_enabled && !s->det;
-  const int k = on && s->ps_capable ? 1 : (on && s->cy_capable ? 2 : 0);
-  if (kind) *kind = k;
-  if (workgroups) *workgroups = k == 1 ? s->mesh.n_blocks : (k == 2 ? s->cy_grid : 0);
-  return SAA_OK;
-}
-
 int saa_resident_kernel_info(const saa_solver *s, int32_t *capable, int32_t *lds_bytes, int32_t *steps_per_launch) {
   if (!s) return fail(SAA_E_ARG, "saa_resident_kernel_info: null handle");
   int32_t chunk = kPersistChunk;
@@ -1514,27 +1338,6 @@ int saa_debug_time_ablated(saa_solver *s, int32_t variant, int32_t nsteps, doubl
   (void)hipEventDestroy(a);
   (void)hipEventDestroy(b);
   return check_launch();
-}
-
-// Diagnostic build only: `nsteps` (<= 1000) steps through the cycling kernel with four wall-clock stamps (100 MHz) per
-// (step, block) task: start, own previous step seen complete, halo records in LDS, progress flag published.
-// tools/cycling_profile.py.
-int saa_debug_cycling_profile(saa_solver *s, int32_t nsteps, long long *stamps_host, int64_t capacity) {
-  const int64_t need = s ? 4ll * nsteps * s->mesh.n_blocks : 0;
-  if (!s || !stamps_host || !s->cy_capable || nsteps < kPersistMinSteps || nsteps > kPersistChunk || capacity < need)
-    return fail(SAA_E_ARG, "saa_debug_cycling_profile: bad argument or no cycling kernel on this handle");
-  HIP_TRY(hipSetDevice(s->device));
-  DevBuf<long long> prof;
-  HIP_TRY(prof.alloc(need));
-  g_cycling_prof = prof.p;
-  int32_t done = 0;
-  const int rc = try_cycling_steps(s, nsteps, &done);
-  g_cycling_prof = nullptr;
-  if (rc) return rc;
-  HIP_TRY(hipStreamSynchronize(s->stream));
-  HIP_TRY(hipMemcpy(stamps_host, prof.p, need * sizeof(long long), hipMemcpyDeviceToHost));
-  prof.release();
-  return done == nsteps ? SAA_OK : fail(SAA_E_STATE, "saa_debug_cycling_profile: the cycling kernel did not take the steps");
 }
 
 #endif  // SAA_DIAGNOSTICS

@@ -125,37 +125,6 @@ struct PersistArgs {
   int32_t *census;          // non-null: census launch - every workgroup checks in here and waits for the full count
 };
 
-// Cycling multi-step kernel (cycling_steps_kernel): for partitions with several plan blocks per workgroup slot (8M tets
-// on one GPU: 2048 blocks, 512 co-resident workgroups).  ONE launch advances the partition by many steps; a workgroup
-// walks through its share of the blocks step after step, running the fused step body on each.  No grid barrier between
-// steps: every block publishes the number of steps it has completed, and a block starts step s as soon as the owners of
-// its halo nodes have completed step s-1.  Work is handed out dynamically: every XCD has a queue of (step, block)
-// tasks over its contiguous run of plan blocks, in step-major order, and its workgroups draw from it with one atomic
-// per task (blocks differ by +-17 % in duration: a fixed assignment runs at the pace of the unluckiest workgroup).
-struct CycleArgs {
-  double *buf[3];           // step s reads d^(n+s) from buf[s % 3], d^(n+s-1) from buf[(s+2) % 3], writes buf[(s+1) % 3]
-  int32_t nsteps;
-  int32_t *queue;           // (8) next task of every XCD's queue; zeroed by the argument kernel of each launch
-  const int32_t *order;     // (n_blocks) position in the XCD runs -> plan block: the order in which a queue hands out the
-                            // blocks of a step (a sweep all queues perform alike, so that neighbouring blocks - in one
-                            // run or across runs - are handed out at about the same point of a step)
-  int32_t *flags;           // (n_blocks) steps completed by that block, counted over all launches of this kernel
-  int32_t flag_base;        // value of every flag at launch
-  const int32_t *halo_blk;  // parallel to DeviceMesh::halo_ids: plan block that owns that halo node
-  double tn0;               // time of d^n at launch
-  int32_t ramp_on;
-  int32_t *err;             // set to 1 when a wait timed out
-  int64_t timeout_ticks;
-  StepConsts consts;
-  int32_t *census;          // non-null: census launch (see PersistArgs::census)
-  long long *prof;          // diagnostic runs: (nsteps, n_blocks, 4) wall-clock stamps (100 MHz) of every task - start,
-                            // own step complete, halo records in LDS, progress flag published - or nullptr
-};
-// How many workgroups of the cycling kernel can be co-resident on the device (0 on error).
-int cycling_max_blocks(int device, int threads, int lds_bytes);
-hipError_t launch_cycling_steps(const DeviceMesh &m, int grid, int threads, int lds_bytes, hipStream_t st, CycleArgs *args_dev,
-                                const CycleArgs &a);
-
 // Recorder of the per-step paths: one small kernel after a step that is due.
 void launch_record_column(int n_nodes, const int32_t *new_to_old, hipStream_t st, const double *d_internal, double *traj,
                           int64_t n_cols, int64_t col);

@@ -337,129 +337,47 @@ __device__ __forceinline__ double peer_collect(const PeerMap *pm, const PeerRecv
 // 2 = no indexed LDS reads, 3 = no staging loads, 4 = no update phase, 5 = no element phase.
 // PEER: synchronised step with the direct peer exchange - shared nodes are pushed to / collected from the
 // neighbour ranks inside this kernel (one launch per step, no collective).
-// State accesses of the step body.  COH (cycling kernel): the state was written by other workgroups - possibly on another
-// XCD - earlier in the SAME launch, so it is read and written with agent-scope relaxed accesses (served by / written
-// through to the level all XCDs share); the order against the owners' progress flags is established by cycle_wait.
-// (explicitly global address space: through a generic pointer these become flat_load/flat_store, which also count on
-// the LDS counter and force full waits around the LDS traffic of the step)
-typedef __attribute__((address_space(1))) double gdouble;
-typedef __attribute__((address_space(1))) int32_t gint32;
-#ifndef SAA_CYC_PLAIN
-#define SAA_CYC_PLAIN 0  // 1 (timing experiments only): plain accesses in the cycling kernel
-#endif
-#ifndef SAA_CYC_NOWAIT
-#define SAA_CYC_NOWAIT 0  // 1 (timing experiments only): no progress flags read, no waits
-#endif
-template <bool COH>
-__device__ __forceinline__ double ld_state(const double *p) {
-  if (COH && !SAA_CYC_PLAIN) return __hip_atomic_load((gdouble *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  return *p;
-}
-template <bool COH>
-__device__ __forceinline__ void st_state(double *p, double v) {
-  if (COH && !SAA_CYC_PLAIN) __hip_atomic_store((gdouble *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  else *p = v;
-}
-__device__ __forceinline__ int32_t ld_flag(const int32_t *p) {
-  return __hip_atomic_load((gint32 *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// Cycling kernel: wait - bounded - until the block behind `flag` has completed `want` steps (`have` = what a load issued
-// earlier already saw).  The loads of that block's displacements are issued after this returns.
-__device__ __forceinline__ void cycle_wait(const CycleArgs *cp, const int32_t *flag, int32_t have, int32_t want) {
-  if (have - want >= 0) return;
-  const long long t0 = wall_clock64();
-  while (ld_flag(flag) - want < 0) {
-    int32_t *errp = cp->err;
-    if (__hip_atomic_load(errp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) break;
-    if (wall_clock64() - t0 > cp->timeout_ticks) {
-      __hip_atomic_store(errp, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      break;
-    }
-    __builtin_amdgcn_s_sleep(2);
-  }
-}
-
-// What a block's step requests first (section 0 of fused_block): connectivity of the first interior sweeps, the global
-// dof index of the lane's first halo dofs and - cycling kernel - the progress flags it will have to look at.  The
-// cycling kernel runs this for the NEXT block before it drains the stores of the current one.
-struct BlockPre {
-  uint2 cpre[kPreConn];
-  int64_t hg[kPreHalo];
-  int32_t hseen[kPreHalo];  // COH: progress of the blocks that own this lane's halo nodes, as seen when requested
-  int32_t own_seen;         // COH: progress of the block itself
-};
-template <bool COH>
-__device__ __forceinline__ void block_prologue(const DeviceMesh &m, const int pblock, const CycleArgs *__restrict__ cp,
-                                               BlockPre &P) {
+template <bool FORCE_ONLY, int ABLATE = 0, bool PEER = false>
+__global__ void __launch_bounds__(SAA_LB) fused_step_kernel(DeviceMesh m, const double *__restrict__ d0, const double *__restrict__ dn,
+                                  double *__restrict__ out, double *__restrict__ iface,
+                                  const double *__restrict__ table_row, double *__restrict__ hist_row, StepConsts k,
+                                  const PeerMap *__restrict__ pmap, unsigned seq) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int pblock = plan_block(blockIdx.x, m.n_blocks);
   const BlockDesc bd = m.blocks[pblock];
-  int tid = threadIdx.x;
-  if (COH) asm volatile("" : "+v"(tid));  // per block and step: nothing derived from it is hoisted out of the loops
-  const int nt = blockDim.x, n_halo3 = 3 * bd.n_halo;
-  const int32_t *hid = m.halo_ids + bd.halo_off;
-  const uint2 *conn = m.conn + bd.elem_off;
-#pragma unroll
-  // All prefetch loads are UNCONDITIONAL with clamped (always valid) indices: loads under a
-  // divergent branch make hipcc fall back to s_waitcnt vmcnt(0) at the first use (the plan pads
-  // conn / halo_ids by one entry so that index 0 exists even for an empty list).
-  for (int j = 0; j < kPreConn; ++j) P.cpre[j] = conn[min(tid + j * nt, max(bd.n_elem - 1, 0))];
-#pragma unroll
-  for (int j = 0; j < kPreHalo; ++j) {
-    const int i = min(tid + j * nt, max(n_halo3 - 1, 0));
-    const int n = i / 3;
-    P.hg[j] = 3 * (int64_t)hid[n] + (i - 3 * n);
-    if (COH && !SAA_CYC_NOWAIT) P.hseen[j] = ld_flag(cp->flags + cp->halo_blk[bd.halo_off + n]);
-  }
-  if (COH && !SAA_CYC_NOWAIT) P.own_seen = ld_flag(cp->flags + pblock);
-}
-
-// One step of one plan block (the body of fused_step_kernel and of cycling_steps_kernel).
-// (`P`: block_prologue of this block.  COH only: `pre` runs before and `post` after the barrier that follows the interior
-// items - the cycling kernel hands the next task over there.)
-template <bool FORCE_ONLY, int ABLATE, bool PEER, bool COH, typename Pre = NoHook, typename Post = NoHook>
-__device__ __forceinline__ void fused_block(const DeviceMesh &m, const int pblock, const double *__restrict__ d0,
-                                            const double *__restrict__ dn, double *__restrict__ out,
-                                            double *__restrict__ iface, const double *__restrict__ table_row,
-                                            double *__restrict__ hist_row, const StepConsts &k,
-                                            const PeerMap *__restrict__ pmap, unsigned seq, double *lds,
-                                            const CycleArgs *__restrict__ cp, int32_t want, const BlockPre &P,
-                                            Pre pre = Pre(), Post post = Post()) {
-  const BlockDesc bd = m.blocks[pblock];
-  int tid = threadIdx.x;
-  if (COH) asm volatile("" : "+v"(tid));  // per block and step: nothing derived from it is hoisted out of the loops
-  // diagnostic runs of the cycling kernel (CycleArgs::prof): wall-clock stamps of wave 0 per (step, block)
-  auto trace = [&](int slot) {
-    if (COH && cp->prof != nullptr && threadIdx.x == 0)
-      cp->prof[4 * ((int64_t)(want - cp->flag_base) * m.n_blocks + pblock) + slot] = wall_clock64();
-  };
-  trace(0);
-  const int nt = blockDim.x;
+  const int tid = threadIdx.x, nt = blockDim.x;
   double *rec = lds;                       // [n_owned + n_halo][6]: x y z ux uy uz
   double *acc = lds + 6 * m.max_local;     // force accumulators [n_owned][3]
   const int n_own3 = 3 * bd.n_owned, n_halo3 = 3 * bd.n_halo;
   const int64_t base = 3 * (int64_t)bd.node_start;
   const int32_t *hid = m.halo_ids + bd.halo_off;
 
-  // ---- 0. interior connectivity and halo ids first (see kPreConn): block_prologue -> P --------------
+  // ---- 0. interior connectivity and halo ids first (see kPreConn) ------------------------------
   unsigned long long T[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tk = 0;
   if (ABLATE == 8) tk = stamp();
   const uint2 *conn = m.conn + bd.elem_off;
-  const uint2 *cpre = P.cpre;
-  const int64_t *hg = P.hg;
-  const int32_t *hseen = P.hseen;
-  auto halo_flag = [&](int i) { return cp->flags + cp->halo_blk[bd.halo_off + i / 3]; };  // of halo dof i
+  uint2 cpre[kPreConn];
+#pragma unroll
+  // All prefetch loads are UNCONDITIONAL with clamped (always valid) indices: loads under a
+  // divergent branch make hipcc fall back to s_waitcnt vmcnt(0) at the first use (the plan pads
+  // conn / halo_ids by one entry so that index 0 exists even for an empty list).
+  for (int j = 0; j < kPreConn; ++j) cpre[j] = conn[min(tid + j * nt, max(bd.n_elem - 1, 0))];
+  int64_t hg[kPreHalo];
+#pragma unroll
+  for (int j = 0; j < kPreHalo; ++j) {
+    const int i = min(tid + j * nt, max(n_halo3 - 1, 0));
+    const int n = i / 3;
+    hg[j] = 3 * (int64_t)hid[n] + (i - 3 * n);
+  }
 
   // ---- 1. owned node records (contiguous) -> LDS; zero the accumulators -------------------------
   {
     const double *xo = m.xyz + base;
     const double *uo = d0 + base;
-    // cycling kernel: the block's own displacements were written by whichever workgroup took its previous step; its
-    // progress flag was requested with the prologue, so this is a register compare unless that step is late
-    if (COH && !SAA_CYC_NOWAIT) cycle_wait(cp, cp->flags + pblock, P.own_seen, want);
-    trace(1);
     for (int i = tid; i < n_own3; i += nt) {
       const int n = i / 3, c = i - 3 * n;
       rec[6 * n + c] = ABLATE == 3 ? 1.0 * i : xo[i];
-      rec[6 * n + 3 + c] = ABLATE == 3 ? 1e-3 * i : ld_state<COH>(uo + i);
+      rec[6 * n + 3 + c] = ABLATE == 3 ? 1e-3 * i : uo[i];
       acc[3 * n + c] = 0.0;
     }
   }
@@ -469,8 +387,7 @@ __device__ __forceinline__ void fused_block(const DeviceMesh &m, const int pbloc
 #pragma unroll
   for (int j = 0; j < kPreHalo; ++j) {
     hx[j] = ABLATE == 3 ? 1.0 * tid : m.xyz[hg[j]];
-    if (COH && !SAA_CYC_NOWAIT && hseen[j] - want < 0) cycle_wait(cp, halo_flag(min(tid + j * nt, max(n_halo3 - 1, 0))), hseen[j], want);
-    hu[j] = ABLATE == 3 ? 1e-3 * tid : ld_state<COH>(d0 + hg[j]);
+    hu[j] = ABLATE == 3 ? 1e-3 * tid : d0[hg[j]];
   }
   double pm_[kPreOwn], pf[kPreOwn], pn[kPreOwn];
   int32_t ptag[kPreOwn];
@@ -480,7 +397,7 @@ __device__ __forceinline__ void fused_block(const DeviceMesh &m, const int pbloc
       const int i = min(tid + j * nt, n_own3 - 1);
       pm_[j] = ABLATE == 4 ? 1.0 : (m.mass_node ? m.mass_node[bd.node_start + i / 3] : m.mass[base + i]);
       pf[j] = ABLATE == 4 ? 0.0 : (m.fext_yz ? (i % 3 == 0 ? 0.0 : m.fext_yz[bd.node_start + i / 3]) : m.fext[base + i]);
-      pn[j] = ABLATE == 4 ? 0.0 : ld_state<COH>(dn + base + i);
+      pn[j] = ABLATE == 4 ? 0.0 : dn[base + i];
       ptag[j] = ABLATE == 4 ? 0 : m.tag[bd.node_start + i / 3];
     }
   }
@@ -537,13 +454,9 @@ __device__ __forceinline__ void fused_block(const DeviceMesh &m, const int pbloc
     const int n = i / 3, c = i - 3 * n;
     const int64_t g = 3 * (int64_t)hid[n] + c;
     rec[6 * (bd.n_owned + n) + c] = m.xyz[g];
-    if (COH && !SAA_CYC_NOWAIT) cycle_wait(cp, halo_flag(i), want - 1, want);
-    rec[6 * (bd.n_owned + n) + 3 + c] = ld_state<COH>(d0 + g);
+    rec[6 * (bd.n_owned + n) + 3 + c] = d0[g];
   }
-  pre();
   lds_barrier();
-  trace(2);
-  post();
 
   // update of one owned dof from its finished force (and publication / prediction for shared nodes)
   auto finish = [&](int i, double mass, double fpre, double dnv, int32_t tag) {
@@ -559,7 +472,7 @@ __device__ __forceinline__ void fused_block(const DeviceMesh &m, const int pbloc
       v = table_row[j];
       if (hist_row != nullptr) hist_row[j] = v;
     }
-    st_state<COH>(out + base + i, v);
+    out[base + i] = v;
   };
   if (ABLATE == 8) {
     const unsigned long long t = stamp();
@@ -621,8 +534,8 @@ __device__ __forceinline__ void fused_block(const DeviceMesh &m, const int pbloc
   }
   for (int i = tid + kPreOwn * nt; i < n_own3; i += nt)
     finish(i, m.mass_node ? m.mass_node[bd.node_start + i / 3] : m.mass[base + i],
-           m.fext_yz ? (i % 3 == 0 ? 0.0 : m.fext_yz[bd.node_start + i / 3]) : m.fext[base + i],
-           ld_state<COH>(dn + base + i), m.tag[bd.node_start + i / 3]);
+           m.fext_yz ? (i % 3 == 0 ? 0.0 : m.fext_yz[bd.node_start + i / 3]) : m.fext[base + i], dn[base + i],
+           m.tag[bd.node_start + i / 3]);
   if (PEER) {
     for (int j = tid; j < n_sh3; j += nt) {
       const int q = sh0 + j / 3, c = j % 3;
@@ -646,110 +559,6 @@ __device__ __forceinline__ void fused_block(const DeviceMesh &m, const int pbloc
                                 12 * ((size_t)blockIdx.x * (nt >> 6) + (tid >> 6));
       for (int j = 0; j < 12; ++j) dbg[j] = T[j];
     }
-  }
-}
-
-template <bool FORCE_ONLY, int ABLATE = 0, bool PEER = false>
-__global__ void __launch_bounds__(SAA_LB) fused_step_kernel(DeviceMesh m, const double *__restrict__ d0, const double *__restrict__ dn,
-                                  double *__restrict__ out, double *__restrict__ iface,
-                                  const double *__restrict__ table_row, double *__restrict__ hist_row, StepConsts k,
-                                  const PeerMap *__restrict__ pmap, unsigned seq) {
-  extern __shared__ __attribute__((aligned(16))) double lds[];
-  // (ABLATE == 9: eight steps' worth of blocks in one launch - what the launch boundary and its tail cost)
-  const int pblock = plan_block(ABLATE == 9 ? blockIdx.x % m.n_blocks : blockIdx.x, m.n_blocks);
-  BlockPre P;
-  block_prologue<false>(m, pblock, nullptr, P);
-  fused_block<FORCE_ONLY, ABLATE, PEER, false>(m, pblock, d0, dn, out, iface, table_row, hist_row, k, pmap, seq, lds,
-                                               nullptr, 0, P);
-}
-
-// Cycling multi-step kernel (saa_device.h: CycleArgs).  Workgroup w sits on XCD w % 8 (round-robin dispatch) and draws
-// (step, block) tasks from that XCD's queue - its contiguous run of plan blocks, step after step - so that the blocks in
-// flight on an XCD are neighbours and share halo lines in its L2.  A block of step s needs d^(n+s) of its halo nodes,
-// written by their owners' step s-1 (cycle_wait on the owners' progress flags inside fused_block); it overwrites the
-// buffer that held d^(n+s-2), which those neighbours - having completed step s-1 - no longer read.
-// Deadlock-free when all workgroups are co-resident (census at set-up): tasks are drawn in step-major order, so the
-// earliest step any workgroup holds (as its current or its reserved next task) has all its dependencies - tasks of the
-// step before - already drawn by workgroups that can finish them.  Every wait is bounded.
-__global__ void __launch_bounds__(SAA_LB) cycling_steps_kernel(DeviceMesh m, const CycleArgs *__restrict__ ap) {
-  extern __shared__ __attribute__((aligned(16))) double lds[];
-  __shared__ int32_t next_task;
-  if (ap->census != nullptr) {  // all workgroups of this grid on the chip at the same time? (see persistent_steps_kernel)
-    if (threadIdx.x == 0) {
-      int32_t *cnt = ap->census;
-      __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const long long t0 = wall_clock64();
-      while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (int32_t)gridDim.x) {
-        if (__hip_atomic_load(ap->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) break;
-        if (wall_clock64() - t0 > ap->timeout_ticks) {
-          __hip_atomic_store(ap->err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-          break;
-        }
-        __builtin_amdgcn_s_sleep(8);
-      }
-    }
-    return;
-  }
-  const int per = m.n_blocks >> 3, rem = m.n_blocks & 7;
-  const int x = blockIdx.x & 7;
-  const int run0 = x * per + (x < rem ? x : rem), cnt = per + (x < rem ? 1 : 0);
-  const int n_tasks = ap->nsteps * cnt;
-  gint32 *queue = (gint32 *)(ap->queue + x);
-  auto draw = [&]() { return __hip_atomic_fetch_add(queue, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-#ifdef SAA_CYC_STAGGER
-  // experiment: workgroups that (presumably) share a CU start half a block apart
-  if ((blockIdx.x * 2 / gridDim.x) & 1) {
-    const long long t0 = wall_clock64();
-    while (wall_clock64() - t0 < SAA_CYC_STAGGER) __builtin_amdgcn_s_sleep(8);
-  }
-#endif
-  const int32_t *order = ap->order + run0;
-  if (threadIdx.x == 0) next_task = draw();
-  __syncthreads();
-  int task = __builtin_amdgcn_readfirstlane(next_task);  // wave-uniform: block descriptor and addresses stay scalar
-  int s_cur = 0;
-  double tn = ap->tn0;
-  BlockPre P;
-  if (task < n_tasks) block_prologue<true>(m, __builtin_amdgcn_readfirstlane(order[task % cnt]), ap, P);
-  while (task < n_tasks) {
-    // The task after this one is drawn now and handed to the whole workgroup half-way through this block (`pre` /
-    // `post` around the barrier behind the interior items).
-    int32_t reserved = 0;
-    if (threadIdx.x == 0) reserved = draw();
-    const int s = task / cnt;
-    const int pblock = __builtin_amdgcn_readfirstlane(order[task - s * cnt]);  // scalar, like blockIdx: what is derived
-                                                                                // from it (descriptor, bounds, bases) too
-    StepConsts k = ap->consts;
-    for (; s_cur < s; ++s_cur) tn = tn + k.dt;  // the host's clock: repeated addition (Data_prepare.py:235)
-    k.ramp = ap->ramp_on ? (tn <= 1 ? tn : 1.0) : 1.0;  // commons.py:7-11 at the time of d^n
-    const int r = s % 3;
-    const double *d0 = ap->buf[r];
-    const double *dn = ap->buf[r == 0 ? 2 : r - 1];
-    double *out = ap->buf[r == 2 ? 0 : r + 1];
-    // the block itself (a different workgroup may have taken its previous step) and the owners of its halo nodes have
-    // completed this many steps
-    const int32_t want = ap->flag_base + s;
-    int next = 0;
-    auto pre = [&]() {
-      if (threadIdx.x == 0) next_task = reserved;
-    };
-    auto post = [&]() { next = __builtin_amdgcn_readfirstlane(next_task); };
-    fused_block<false, 0, false, true>(m, pblock, d0, dn, out, nullptr, nullptr, nullptr, k, nullptr, 0u, lds, ap, want, P,
-                                       pre, post);
-    // The next block's first requests (connectivity, halo indices, progress flags) go out BEFORE this block's stores
-    // are drained: one wait covers both.  The new displacements are agent-scope write-through stores - complete when
-    // acknowledged - and the progress flag moves after every wave has seen its own acknowledged.  (A release fence
-    // would add an L2 write-back - buffer_wbl2 - per block with nothing of ours to write back: 440 against 85 us/step.)
-    if (next < n_tasks) block_prologue<true>(m, __builtin_amdgcn_readfirstlane(order[next % cnt]), ap, P);
-#if !defined(SAA_CYC_NODRAIN)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-    __syncthreads();  // also keeps the next block's staging out of the LDS image until the last wave has left the update
-    if (threadIdx.x == 0) {
-      __hip_atomic_store((gint32 *)(ap->flags + pblock), want + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (ap->prof != nullptr) ap->prof[4 * ((int64_t)s * m.n_blocks + pblock) + 3] = wall_clock64();
-    }
-    task = next;
   }
 }
 
@@ -1290,43 +1099,16 @@ void launch_fused_step_ablated(int variant, const DeviceMesh &m, int threads, in
   case V:                                                                                                  \
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_step_kernel<false, V>),                \
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);                      \
-    hipLaunchKernelGGL((fused_step_kernel<false, V>), dim3(V == 9 ? 8 * m.n_blocks : m.n_blocks), dim3(threads), lds_bytes, st, m, d0, \
+    hipLaunchKernelGGL((fused_step_kernel<false, V>), dim3(m.n_blocks), dim3(threads), lds_bytes, st, m, d0, \
                        dn, d1, none, cnone, V == 8 ? dbg : none, k, static_cast<const PeerMap *>(nullptr), 0u); \
     break;
   switch (variant) {
-    SAA_ABL(0) SAA_ABL(1) SAA_ABL(2) SAA_ABL(3) SAA_ABL(4) SAA_ABL(5) SAA_ABL(6) SAA_ABL(7) SAA_ABL(8) SAA_ABL(9)
+    SAA_ABL(0) SAA_ABL(1) SAA_ABL(2) SAA_ABL(3) SAA_ABL(4) SAA_ABL(5) SAA_ABL(6) SAA_ABL(7) SAA_ABL(8)
     default: break;
   }
 #undef SAA_ABL
 }
 #endif  // SAA_DIAGNOSTICS
-
-__global__ void cycle_args_kernel(CycleArgs *dst, CycleArgs a) {
-  *dst = a;
-  if (a.queue != nullptr)
-    for (int x = 0; x < 8; ++x) a.queue[x] = 0;
-}
-
-hipError_t launch_cycling_steps(const DeviceMesh &m, int grid, int threads, int lds_bytes, hipStream_t st, CycleArgs *args_dev,
-                                const CycleArgs &a) {
-  hipLaunchKernelGGL(cycle_args_kernel, dim3(1), dim3(1), 0, st, args_dev, a);
-  const CycleArgs *ap = args_dev;
-  hipLaunchKernelGGL(cycling_steps_kernel, dim3(grid), dim3(threads), lds_bytes, st, m, ap);
-  return hipGetLastError();
-}
-
-int cycling_max_blocks(int device, int threads, int lds_bytes) {
-  const void *fn = reinterpret_cast<const void *>(&cycling_steps_kernel);
-  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess) return 0;
-  int per_cu = 0, cus = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, cycling_steps_kernel, threads, lds_bytes) != hipSuccess) return 0;
-  // same scalar-register rule as persistent_max_blocks (the census launch is the proof either way)
-  constexpr int kSgprBand = 112, kWavesPerSimd = 800 / (kSgprBand + 16) < 8 ? 800 / (kSgprBand + 16) : 8;
-  const int by_sgpr = threads >= 256 ? kWavesPerSimd / (threads / 256) : kWavesPerSimd * (256 / threads);
-  per_cu = per_cu < by_sgpr ? per_cu : by_sgpr;
-  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) return 0;
-  return per_cu * cus;
-}
 
 int persistent_lds_bytes(int max_local, int max_owned, int max_items, int max_halo) {
   const int fstride = force_stride_for(max_owned);

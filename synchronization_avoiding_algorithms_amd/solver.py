@@ -109,12 +109,6 @@ class HipExplicitSolver:
         _lib.check(self._lib.saa_resident_kernel_info(self._h, C.byref(cap), C.byref(lds), C.byref(spl)))
         return {"capable": bool(cap.value), "lds_bytes": lds.value, "steps_per_launch": spl.value}
 
-    def multistep_kernel_info(self) -> dict:
-        """How plain multi-step calls run: ``per_step`` launches, the ``resident`` kernel or the ``cycling`` kernel."""
-        kind, wgs = C.c_int32(), C.c_int32()
-        _lib.check(self._lib.saa_multistep_kernel_info(self._h, C.byref(kind), C.byref(wgs)))
-        return {"kind": ("per_step", "resident", "cycling")[kind.value], "workgroups": wgs.value}
-
     def set_recorder(self, traj=None, save_every=1, next_step_index=0):
         """``traj``: float64 CUDA tensor ``(3*n_nodes, n_cols)`` (kept alive by the caller) that receives the
         displacement of every ``save_every``-th step, like ``d1_save`` of ``Data_prepare.py:236-240``; ``None``
