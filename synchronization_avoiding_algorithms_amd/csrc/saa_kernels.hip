@@ -343,7 +343,8 @@ __global__ void __launch_bounds__(SAA_LB) fused_step_kernel(DeviceMesh m, const 
                                   const double *__restrict__ table_row, double *__restrict__ hist_row, StepConsts k,
                                   const PeerMap *__restrict__ pmap, unsigned seq) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  const int pblock = plan_block(blockIdx.x, m.n_blocks);
+  // (ABLATE == 9: eight steps' worth of blocks in one launch - what the launch boundary and its tail cost)
+  const int pblock = plan_block(ABLATE == 9 ? blockIdx.x % m.n_blocks : blockIdx.x, m.n_blocks);
   const BlockDesc bd = m.blocks[pblock];
   const int tid = threadIdx.x, nt = blockDim.x;
   double *rec = lds;                       // [n_owned + n_halo][6]: x y z ux uy uz
@@ -1099,11 +1100,11 @@ void launch_fused_step_ablated(int variant, const DeviceMesh &m, int threads, in
   case V:                                                                                                  \
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_step_kernel<false, V>),                \
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);                      \
-    hipLaunchKernelGGL((fused_step_kernel<false, V>), dim3(m.n_blocks), dim3(threads), lds_bytes, st, m, d0, \
+    hipLaunchKernelGGL((fused_step_kernel<false, V>), dim3(V == 9 ? 8 * m.n_blocks : m.n_blocks), dim3(threads), lds_bytes, st, m, d0, \
                        dn, d1, none, cnone, V == 8 ? dbg : none, k, static_cast<const PeerMap *>(nullptr), 0u); \
     break;
   switch (variant) {
-    SAA_ABL(0) SAA_ABL(1) SAA_ABL(2) SAA_ABL(3) SAA_ABL(4) SAA_ABL(5) SAA_ABL(6) SAA_ABL(7) SAA_ABL(8)
+    SAA_ABL(0) SAA_ABL(1) SAA_ABL(2) SAA_ABL(3) SAA_ABL(4) SAA_ABL(5) SAA_ABL(6) SAA_ABL(7) SAA_ABL(8) SAA_ABL(9)
     default: break;
   }
 #undef SAA_ABL

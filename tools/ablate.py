@@ -26,10 +26,11 @@ lib = _lib.load()
 lib.saa_debug_time_ablated.restype = C.c_int
 lib.saa_debug_time_ablated.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_double)]
 names = {0: "full", 1: "no LDS atomics", 2: "no indexed LDS reads", 3: "no staging loads",
-         4: "no update phase", 5: "no element phase", 6: "element VALU only", 7: "element LDS only"}
+         4: "no update phase", 5: "no element phase", 6: "element VALU only", 7: "element LDS only",
+         9: "8 steps of blocks, 1 launch"}
 print("plan", sol.plan_stats())
 ms = C.c_double()
-for v in (0, 1, 2, 3, 4, 5, 6, 7, 0):
+for v in (0, 1, 2, 3, 4, 5, 6, 7, 9, 0):
     lib.saa_debug_time_ablated(sol._h, v, 200, C.byref(ms))
     lib.saa_debug_time_ablated(sol._h, v, 1000, C.byref(ms))
     print(f"variant {v} ({names[v]:22s}): {ms.value:8.3f} us/launch")
