@@ -123,7 +123,6 @@ struct saa_solver {
   // resident multi-step kernel (saa_device.h: PersistArgs)
   DevBuf<int32_t> ps_err;
   DevBuf<saa::PeerEntry> ps_entries;  // 2 x 3*n_nodes stamped displacements
-  DevBuf<saa::PersistArgs> ps_args;   // argument block of the launch in flight
   int32_t ps_lds = 0, ps_max_items = 0, ps_steps = 0;
   bool ps_capable = false;  // plan fits LDS and all workgroups can be co-resident
   bool ps_enabled = true;   // saa_set_resident_kernel
@@ -174,7 +173,7 @@ struct saa_solver {
     sh_slot.release(); sh_foreign.release(); slot_sidx.release(); conn.release(); xyz.release(); mass.release(); fext.release(); mass_node.release(); fext_yz.release();
     for (auto &b : dbuf) b.release();
     for (auto &b : scratch) b.release();
-    ps_entries.release(); ps_err.release(); ps_args.release();
+    ps_entries.release(); ps_err.release();
     det_force.release(); det_off.release(); det_contrib.release();
     for (void *q : peer_open) (void)hipIpcCloseMemHandle(q);
     peer_open.clear();
@@ -347,7 +346,7 @@ void setup_persistent(saa_solver *s) {
   const int max_blocks = saa::persistent_max_blocks(s->device, s->threads, lds);
   if (max_blocks <= 0 || (max_blocks < nb && !(trust && trust[0] == '1'))) return;
   const size_t n_entries = 2 * 3 * static_cast<size_t>(plan.n_nodes);
-  if (s->ps_entries.alloc(n_entries) != hipSuccess || s->ps_args.alloc(1) != hipSuccess || s->ps_err.upload(std::vector<int32_t>(1, 0)) != hipSuccess ||
+  if (s->ps_entries.alloc(n_entries) != hipSuccess || s->ps_err.upload(std::vector<int32_t>(1, 0)) != hipSuccess ||
       hipMemset(s->ps_entries.p, 0, n_entries * sizeof(saa::PeerEntry)) != hipSuccess) {  // stamp 0 = never written
     (void)hipGetLastError();
     s->ps_entries.release();
@@ -367,7 +366,7 @@ void setup_persistent(saa_solver *s) {
     a.err = s->ps_err.p;
     a.timeout_ticks = 5000000;  // 50 ms of the 100 MHz wall clock
     a.max_items = max_items;
-    ok = ok && saa::launch_persistent_steps(s->mesh, s->threads, lds, s->stream, s->consts, s->ps_args.p, a, 0) == hipSuccess;
+    ok = ok && saa::launch_persistent_steps(s->mesh, s->threads, lds, s->stream, s->consts, a, 0) == hipSuccess;
     ok = ok && hipStreamSynchronize(s->stream) == hipSuccess;
     int32_t e = 1, seen = 0;
     ok = ok && hipMemcpy(&e, s->ps_err.p, sizeof(e), hipMemcpyDeviceToHost) == hipSuccess &&
@@ -433,8 +432,8 @@ int try_persistent_steps(saa_solver *s, int32_t nsteps, const double *table_dev,
     a.traj_cols = s->rec_cols;
     a.step_index0 = s->rec_index;
     a.save_every = s->rec_every;
-    const hipError_t e = saa::launch_persistent_steps(s->mesh, s->threads, s->ps_lds, s->stream, s->consts,
-                                                      s->ps_args.p, a, peer ? 2 : (table_dev != nullptr ? 1 : 0));
+    const hipError_t e = saa::launch_persistent_steps(s->mesh, s->threads, s->ps_lds, s->stream, s->consts, a,
+                                                      peer ? 2 : (table_dev != nullptr ? 1 : 0));
     if (e != hipSuccess) {  // e.g. the device cannot hold all workgroups right now: keep the per-step path
       (void)hipGetLastError();
       s->ps_capable = false;

@@ -132,9 +132,9 @@ void launch_record_column(int n_nodes, const int32_t *new_to_old, hipStream_t st
 int persistent_lds_bytes(int max_local, int max_owned, int max_items, int max_halo);
 // How many workgroups of the resident kernel can be co-resident on the device (0 on error).
 int persistent_max_blocks(int device, int threads, int lds_bytes);
-// Writes `a` to the device-side argument block (a one-thread kernel, stream-ordered) and launches the resident kernel.
+// Launches the resident kernel; `a` travels by value in the kernel-argument segment.
 hipError_t launch_persistent_steps(const DeviceMesh &m, int threads, int lds_bytes, hipStream_t st, const StepConsts &k,
-                                   PersistArgs *args_dev, const PersistArgs &a, int mode);
+                                   const PersistArgs &a, int mode);
 
 hipError_t configure_kernels(int lds_bytes);
 hipError_t configure_det_kernels(int lds_bytes);

@@ -21,6 +21,7 @@
 // gfx950 anyway).  64-wide waves; cross-workgroup data flows through kernel boundaries (cross-RANK data of the
 // PEER variant through self-validating entries in fine-grained memory).
 #include <hip/hip_runtime.h>
+#include <cstddef>
 #include <stdint.h>
 
 #include "saa_device.h"
@@ -614,10 +615,28 @@ constexpr int kPH = SAA_PERSIST_PRE;  // stamped halo entries per thread in flig
 // kernel's scalar registers.  The argument block is read from device memory where it is needed for the same reason.
 // PEER: synchronised steps with the direct peer exchange (shared nodes pushed to / collected from the neighbour
 // ranks inside the step loop, like fused_step_kernel<.., PEER>).
+// The argument block travels BY VALUE in the kernel-argument segment (no separate kernel or copy to place it in device
+// memory: 4.8 of the 183 us of a 20-step call) but is read through an opaque constant-address-space pointer into that
+// segment, field by field where needed: named as a parameter the compiler loads it up front and holds ~60 scalar
+// registers through the item loops, which have none to spare.
+struct PersistKernArgs {  // layout of the kernel-argument segment
+  DeviceMesh m;
+  StepConsts k;
+  PersistArgs a;
+};
+typedef const __attribute__((address_space(4))) PersistArgs *PersistArgsPtr;
+typedef const __attribute__((address_space(4))) StepConsts *StepConstsPtr;
 template <bool PREDICT, bool PEER>
-__global__ void __launch_bounds__(SAA_LB) persistent_steps_kernel(DeviceMesh m, StepConsts k,
-                                                                  const PersistArgs *__restrict__ ap) {
+__global__ void __launch_bounds__(SAA_LB) persistent_steps_kernel(DeviceMesh m, StepConsts k, PersistArgs /*see ap*/) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
+  PersistArgsPtr ap;
+  {
+    const __attribute__((address_space(4))) char *seg =
+        (const __attribute__((address_space(4))) char *)__builtin_amdgcn_kernarg_segment_ptr();
+    seg += offsetof(PersistKernArgs, a);
+    asm volatile("" : "+s"(seg));
+    ap = reinterpret_cast<PersistArgsPtr>(seg);
+  }
   struct {
     double *g0, *g1;
     PeerEntry *entries;
@@ -638,8 +657,13 @@ __global__ void __launch_bounds__(SAA_LB) persistent_steps_kernel(DeviceMesh m, 
   int32_t *tagl = reinterpret_cast<int32_t *>(connl + a.max_items);
   int32_t *hgl = tagl + m.max_owned;  // [3 * max_halo] entry index 3*node+c of every halo dof
   const int n_own3 = 3 * bd.n_owned, n_halo3 = 3 * bd.n_halo;
-  const int64_t base = 3 * (int64_t)bd.node_start;
+  int64_t base = 3 * (int64_t)bd.node_start;
   const int32_t *hid = m.halo_ids + bd.halo_off;
+  if (PEER) {
+    // the variant shortest of scalar registers keeps what only the halo and update phases use - wave-uniform values -
+    // in vector registers, of which it has a dozen to spare
+    asm volatile("" : "+v"(dnl), "+v"(massl), "+v"(fextl), "+v"(tagl), "+v"(hgl), "+v"(base));
+  }
 
   // ---- census launch (once per handle, at set-up): are ALL workgroups of this grid on the chip at the same time?
   //      Every workgroup checks in and waits - bounded - until the count is complete.  The launch is a plain one (the
@@ -699,15 +723,17 @@ __global__ void __launch_bounds__(SAA_LB) persistent_steps_kernel(DeviceMesh m, 
 #define PSTAMP(j)
 #endif
   for (int s = 0; s < a.nsteps; ++s) {
-    const double ramp_now = a.ramp_on ? (tn <= 1 ? tn : 1.0) : 1.0;  // commons.py:7-11 at the time of d^n
+    PersistArgsPtr ah = ap;  // (PEER: opaque once per step, see the update phase)
+    if (PEER) asm volatile("" : "+s"(ah));
+    const double ramp_now = ah->ramp_on ? (tn <= 1 ? tn : 1.0) : 1.0;  // commons.py:7-11 at the time of d^n
     if (!PEER) k.ramp = ramp_now;
     // Opaque copy of the thread index for the halo and update phases: whatever is derived from it is recomputed
     // every step.  Derived from `tid` the compiler hoists those per-thread constants (indices, addresses) out of
     // the step loop, keeps them alive through the item loops and spills.
     int ltid = tid;
     asm volatile("" : "+v"(ltid));
-    const unsigned want = (unsigned)(a.step_base + s);  // stamp of d^(n+s), written by its owner in step s-1
-    const PeerEntry *ein = a.entries + (int64_t)(s & 1) * a.entry_stride;
+    const unsigned want = (unsigned)(ah->step_base + s);  // stamp of d^(n+s), written by its owner in step s-1
+    const PeerEntry *ein = ah->entries + (int64_t)(s & 1) * ah->entry_stride;
     // ---- 1. first round: interior items; the halo displacements are requested half-way through it (late enough
     //         for the neighbours' stores of the previous step to have landed, early enough to arrive by its end) --
     unsigned long long hlo[kPH], hhi[kPH];
@@ -735,9 +761,9 @@ __global__ void __launch_bounds__(SAA_LB) persistent_steps_kernel(DeviceMesh m, 
           const PeerEntry *e = ein + hgl[i];
           const long long t0 = wall_clock64();
           do {
-            int32_t *errp = *(int32_t *volatile const *)&ap->err;
+            int32_t *errp = *(int32_t *volatile const __attribute__((address_space(4))) *)&ap->err;
             if (__hip_atomic_load(errp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) break;  // failed before
-            if (wall_clock64() - t0 > *(volatile const int64_t *)&ap->timeout_ticks) {
+            if (wall_clock64() - t0 > *(volatile const __attribute__((address_space(4))) int64_t *)&ap->timeout_ticks) {
               // workgroups not co-resident, or a fault elsewhere: report, do not hang
               __hip_atomic_store(errp, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
               break;
@@ -780,32 +806,37 @@ __global__ void __launch_bounds__(SAA_LB) persistent_steps_kernel(DeviceMesh m, 
     PSTAMP(5)
     // ---- 5. update of the owned dofs: LDS operands; the new value leaves as a plain double (state) and as a
     //         stamped entry (what the neighbouring workgroups read in the next step) ------------------------
-    double *gnext = (s & 1) ? a.g0 : a.g1;
-    PeerEntry *eout = a.entries + (int64_t)((s + 1) & 1) * a.entry_stride + base;
-    const unsigned stampw = (unsigned)(a.step_base + s + 1);
+    // (PEER, the variant shortest of scalar registers: the argument block is addressed through a pointer made opaque once
+    // per step, so that its fields are loaded here, where they are used, instead of being held through the item loops;
+    // the other variants let the compiler hoist these loads out of the step loop)
+    PersistArgsPtr aq = ap;
+    if (PEER) asm volatile("" : "+s"(aq));
+    double *gnext = (s & 1) ? aq->g0 : aq->g1;
+    PeerEntry *eout = aq->entries + (int64_t)((s + 1) & 1) * aq->entry_stride + base;
+    const unsigned stampw = (unsigned)(aq->step_base + s + 1);
     asm volatile("" : "+v"(ltid));
     // the state buffers only need the last two steps of the launch (d^n and d^(n-1) for whoever comes next)
-    const bool keep = s + 2 >= a.nsteps;
+    const bool keep = s + 2 >= aq->nsteps;
     // new value of owned dof i: state buffer, stamped entry for the neighbouring workgroups, LDS image
     // trajectory recorder: is this step's result a column of the caller's matrix?
     double *traj_col = nullptr;
     int64_t traj_ld = 0;
-    if (ap->traj != nullptr) {
-      const int64_t idx = ap->step_index0 + s, every = ap->save_every;
-      if (idx % every == 0 && idx / every < ap->traj_cols) {
-        traj_col = ap->traj + idx / every;
-        traj_ld = ap->traj_cols;
+    if (aq->traj != nullptr) {
+      const int64_t idx = aq->step_index0 + s, every = aq->save_every;
+      if (idx % every == 0 && idx / every < aq->traj_cols) {
+        traj_col = aq->traj + idx / every;
+        traj_ld = aq->traj_cols;
       }
     }
     if (PEER) {  // step constants from the argument block, not from registers held since the launch
-      const StepConsts *kp = &ap->consts;
+      StepConstsPtr kp = &aq->consts;
       asm volatile("" : "+s"(kp));
-      k = *kp;
+      k.dt = kp->dt; k.dt2 = kp->dt2; k.half_dt = kp->half_dt; k.alpha = kp->alpha; k.half_alpha = kp->half_alpha;
       k.ramp = ramp_now;
     }
     auto commit = [&](int i, int n, int c, double u, double v) {
       if (keep) gnext[base + i] = v;
-      if (traj_col != nullptr) traj_col[(3 * (int64_t)ap->new_to_old[bd.node_start + n] + c) * traj_ld] = v;
+      if (traj_col != nullptr) traj_col[(3 * (int64_t)aq->new_to_old[bd.node_start + n] + c) * traj_ld] = v;
       {
         // one 16-byte store, agent scope (write-through to the level all XCDs share); each half validates itself
         const unsigned long long b = (unsigned long long)__double_as_longlong(v);
@@ -821,8 +852,8 @@ __global__ void __launch_bounds__(SAA_LB) persistent_steps_kernel(DeviceMesh m, 
     int sh0 = 0, n_sh3 = 0;
     unsigned pseq = 0;
     if (PEER) {
-      const PeerMap *pm = ap->peer;
-      pseq = ap->peer_seq_base + (unsigned)s + 1u;  // the host keeps a launch clear of the wrap to 0 ("never written")
+      const PeerMap *pm = aq->peer;
+      pseq = aq->peer_seq_base + (unsigned)s + 1u;  // the host keeps a launch clear of the wrap to 0 ("never written")
       sh0 = pm->blk_off[pblock];
       n_sh3 = 3 * (pm->blk_off[pblock + 1] - sh0);
       for (int j = ltid; j < n_sh3; j += nt) {
@@ -843,14 +874,14 @@ __global__ void __launch_bounds__(SAA_LB) persistent_steps_kernel(DeviceMesh m, 
       if (tag & (1 << c)) v = 0.0;  // d1[Local_Dirichlet] = 0   (Dynamic_solver.py:20)
       if (PREDICT && (tag & kTagShared)) {
         // predicted phase: d1[loc_dof_shared] = prediction, recorded as history (Online_predictor.py:298,301)
-        const int64_t j = 3 * (int64_t)m.slot_sidx[tag >> kTagSlotShift] + c, w = ap->width;
-        v = ap->table[(ap->table_row0 + s) * w + j];
-        if (ap->hist != nullptr) ap->hist[(ap->hist_row0 + s) * w + j] = v;
+        const int64_t j = 3 * (int64_t)m.slot_sidx[tag >> kTagSlotShift] + c, w = aq->width;
+        v = aq->table[(aq->table_row0 + s) * w + j];
+        if (aq->hist != nullptr) aq->hist[(aq->hist_row0 + s) * w + j] = v;
       }
       commit(i, n, c, u, v);
     }
     if (PEER) {
-      const PeerMap *pm = ap->peer;
+      const PeerMap *pm = aq->peer;
       for (int j = ltid; j < n_sh3; j += nt) {
         const int q = sh0 + j / 3, c = j % 3;
         const PeerRecvRec r = pm->recv_rec[q];
@@ -859,7 +890,7 @@ __global__ void __launch_bounds__(SAA_LB) persistent_steps_kernel(DeviceMesh m, 
         const double u = rec[6 * n + 3 + c];
         double v = cd_update_dof(f, c == 0 ? 0.0 : fextl[n], massl[n], u, dnl[i], k);  // Dynamic_solver.py:26-32
         if (tagl[n] & (1 << c)) v = 0.0;
-        if (ap->hist != nullptr) ap->hist[(ap->hist_row0 + s) * ap->width + 3 * (int64_t)r.sidx + c] = v;  // Online_predictor.py:260
+        if (aq->hist != nullptr) aq->hist[(aq->hist_row0 + s) * aq->width + 3 * (int64_t)r.sidx + c] = v;  // Online_predictor.py:260
         commit(i, n, c, u, v);
       }
     }
@@ -1143,23 +1174,20 @@ int persistent_max_blocks(int device, int threads, int lds_bytes) {
   return per_cu * cus;
 }
 
-// The argument block of the next resident launch, written by a one-thread kernel: the values travel in the kernel
-// argument segment (captured when the launch is enqueued), so nothing on the host has to outlive the call and nothing is
-// staged through pageable memory; stream order puts the write after the previous launch has finished with the block.
-__global__ void persist_args_kernel(PersistArgs *dst, PersistArgs a) { *dst = a; }
-
+// The argument block travels in the kernel-argument segment (captured when the launch is enqueued): nothing on the host
+// has to outlive the call, nothing is staged through pageable memory, no second launch.
 hipError_t launch_persistent_steps(const DeviceMesh &m, int threads, int lds_bytes, hipStream_t st, const StepConsts &k,
-                                   PersistArgs *args_dev, const PersistArgs &a, int mode) {
-  hipLaunchKernelGGL(persist_args_kernel, dim3(1), dim3(1), 0, st, args_dev, a);
-  const PersistArgs *ap = args_dev;
+                                   const PersistArgs &a, int mode) {
+  static_assert(offsetof(PersistKernArgs, a) == sizeof(DeviceMesh) + sizeof(StepConsts) && alignof(PersistArgs) == 8,
+                "kernel-argument segment: the argument block follows the mesh and the step constants without padding");
   // mode 0: plain steps, 1: predicted phase, 2: synchronised steps with the peer exchange.  Plain launches: co-residency
   // of the grid was established by the census launch at set-up (persistent_census), every wait in the kernel is bounded.
   if (mode == 1)
-    hipLaunchKernelGGL((persistent_steps_kernel<true, false>), dim3(m.n_blocks), dim3(threads), lds_bytes, st, m, k, ap);
+    hipLaunchKernelGGL((persistent_steps_kernel<true, false>), dim3(m.n_blocks), dim3(threads), lds_bytes, st, m, k, a);
   else if (mode == 2)
-    hipLaunchKernelGGL((persistent_steps_kernel<false, true>), dim3(m.n_blocks), dim3(threads), lds_bytes, st, m, k, ap);
+    hipLaunchKernelGGL((persistent_steps_kernel<false, true>), dim3(m.n_blocks), dim3(threads), lds_bytes, st, m, k, a);
   else
-    hipLaunchKernelGGL((persistent_steps_kernel<false, false>), dim3(m.n_blocks), dim3(threads), lds_bytes, st, m, k, ap);
+    hipLaunchKernelGGL((persistent_steps_kernel<false, false>), dim3(m.n_blocks), dim3(threads), lds_bytes, st, m, k, a);
   return hipGetLastError();
 }
 
