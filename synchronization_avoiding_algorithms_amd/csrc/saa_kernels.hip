@@ -650,20 +650,26 @@ __global__ void __launch_bounds__(SAA_LB) persistent_steps_kernel(DeviceMesh m, 
   const int fstride = m.force_stride;
   double *rec = lds;
   double *acc = lds + 6 * m.max_local;
-  double *dnl = lds + persist_off_dn(m.max_local, fstride);
-  double *massl = dnl + 3 * m.max_owned;
-  double *fextl = massl + m.max_owned;
-  uint2 *connl = reinterpret_cast<uint2 *>(fextl + m.max_owned);
-  int32_t *tagl = reinterpret_cast<int32_t *>(connl + a.max_items);
-  int32_t *hgl = tagl + m.max_owned;  // [3 * max_halo] entry index 3*node+c of every halo dof
-  const int n_own3 = 3 * bd.n_owned, n_halo3 = 3 * bd.n_halo;
+  // offsets (in doubles) of the arrays behind the accumulators
+  int o_dn = persist_off_dn(m.max_local, fstride), o_mass = o_dn + 3 * m.max_owned, o_fext = o_mass + m.max_owned,
+      o_conn = o_fext + m.max_owned;
   int64_t base = 3 * (int64_t)bd.node_start;
-  const int32_t *hid = m.halo_ids + bd.halo_off;
   if (PEER) {
     // the variant shortest of scalar registers keeps what only the halo and update phases use - wave-uniform values -
-    // in vector registers, of which it has a dozen to spare
-    asm volatile("" : "+v"(dnl), "+v"(massl), "+v"(fextl), "+v"(tagl), "+v"(hgl), "+v"(base));
+    // in vector registers, of which it has a dozen to spare (the OFFSETS, not the pointers: an opaque pointer is a generic
+    // one, and the LDS arrays behind it would be read with flat loads)
+    asm volatile("" : "+v"(o_dn), "+v"(o_mass), "+v"(o_fext), "+v"(base));
   }
+  double *dnl = lds + o_dn;
+  double *massl = lds + o_mass;
+  double *fextl = lds + o_fext;
+  uint2 *connl = reinterpret_cast<uint2 *>(lds + o_conn);
+  int o_tag = 2 * (o_conn + a.max_items), o_hg = o_tag + m.max_owned;  // in 4-byte words
+  if (PEER) asm volatile("" : "+v"(o_tag), "+v"(o_hg));
+  int32_t *tagl = reinterpret_cast<int32_t *>(lds) + o_tag;
+  int32_t *hgl = reinterpret_cast<int32_t *>(lds) + o_hg;  // [3 * max_halo] entry index 3*node+c of every halo dof
+  const int n_own3 = 3 * bd.n_owned, n_halo3 = 3 * bd.n_halo;
+  const int32_t *hid = m.halo_ids + bd.halo_off;
 
   // ---- census launch (once per handle, at set-up): are ALL workgroups of this grid on the chip at the same time?
   //      Every workgroup checks in and waits - bounded - until the count is complete.  The launch is a plain one (the
@@ -802,19 +808,17 @@ __global__ void __launch_bounds__(SAA_LB) persistent_steps_kernel(DeviceMesh m, 
       if (e >= 0) item_forces<0>(connl[e], rec, acc, bd.n_owned, m.lambda_, m.mu, tid, sink);
     }
     PSTAMP(4)
-    lds_barrier();
-    PSTAMP(5)
     // ---- 5. update of the owned dofs: LDS operands; the new value leaves as a plain double (state) and as a
     //         stamped entry (what the neighbouring workgroups read in the next step) ------------------------
     // (PEER, the variant shortest of scalar registers: the argument block is addressed through a pointer made opaque once
-    // per step, so that its fields are loaded here, where they are used, instead of being held through the item loops;
-    // the other variants let the compiler hoist these loads out of the step loop)
+    // per step, so that its fields are loaded here, where they are used, instead of being held through the item loops -
+    // requested in front of the barrier, whose wait covers their latency; the other variants let the compiler hoist
+    // these loads out of the step loop)
     PersistArgsPtr aq = ap;
     if (PEER) asm volatile("" : "+s"(aq));
     double *gnext = (s & 1) ? aq->g0 : aq->g1;
     PeerEntry *eout = aq->entries + (int64_t)((s + 1) & 1) * aq->entry_stride + base;
     const unsigned stampw = (unsigned)(aq->step_base + s + 1);
-    asm volatile("" : "+v"(ltid));
     // the state buffers only need the last two steps of the launch (d^n and d^(n-1) for whoever comes next)
     const bool keep = s + 2 >= aq->nsteps;
     // new value of owned dof i: state buffer, stamped entry for the neighbouring workgroups, LDS image
@@ -834,6 +838,9 @@ __global__ void __launch_bounds__(SAA_LB) persistent_steps_kernel(DeviceMesh m, 
       k.dt = kp->dt; k.dt2 = kp->dt2; k.half_dt = kp->half_dt; k.alpha = kp->alpha; k.half_alpha = kp->half_alpha;
       k.ramp = ramp_now;
     }
+    lds_barrier();
+    PSTAMP(5)
+    asm volatile("" : "+v"(ltid));
     auto commit = [&](int i, int n, int c, double u, double v) {
       if (keep) gnext[base + i] = v;
       if (traj_col != nullptr) traj_col[(3 * (int64_t)aq->new_to_old[bd.node_start + n] + c) * traj_ld] = v;
