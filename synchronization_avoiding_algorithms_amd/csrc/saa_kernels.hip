@@ -753,8 +753,9 @@ __global__ void __launch_bounds__(SAA_LB) persistent_steps_kernel(DeviceMesh m, 
         }
       }
     };
+    // (interior items: the variant of the item code without ownership tests)
     if (tid < n_pre)
-      item_forces<0>(connl[tid], rec, acc, bd.n_owned, m.lambda_, m.mu, tid, sink, nullptr, fetch);
+      item_forces<0, decltype(fetch), true>(connl[tid], rec, acc, bd.n_owned, m.lambda_, m.mu, tid, sink, nullptr, fetch);
     else
       fetch();
     PSTAMP(0)
@@ -801,8 +802,8 @@ __global__ void __launch_bounds__(SAA_LB) persistent_steps_kernel(DeviceMesh m, 
     //         partly filled round between them -----------------------------------------------------------------
     //         The boundary part starts on a wave boundary (the interior part is padded to a multiple of 64 slots):
     //         the plan packed each list for the LDS banks from ITS first item, in groups of 16 / 32 lanes.
-    //         (the ownership-test-free variant of the interior items, which the fused kernel uses, was measured here
-    //         too: 8.82 against 8.57 us/step - two inlined copies of the item code cost this kernel its last registers)
+    //         (the ownership-test-free variant of the interior items, which the first round and the fused kernel use,
+    //         was measured here too, behind a wave-uniform branch: 8.60-8.67 against 8.43 us/step)
     for (int p = tid; p < n_post; p += nt) {
       const int e = p < n_ir_pad ? (p < n_ir ? n_pre + p : -1) : bd.n_interior + (p - n_ir_pad);
       if (e >= 0) item_forces<0>(connl[e], rec, acc, bd.n_owned, m.lambda_, m.mu, tid, sink);
