@@ -1,0 +1,33 @@
+"""Register budget of the gfx950 step kernels (compile-time facts: no GPU needed).  The step kernels run at four waves per
+SIMD (1024-thread workgroups, one per CU, or two 512-thread ones): 128 VGPRs is the ceiling, and a spill of either kind
+or any scratch use is a performance regression that no parity test would notice (27 scalar spills in the
+PEER variant of the resident kernel)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="hipcc not installed")
+def test_step_kernels_fit_their_register_budget_without_spills():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "kernel_resources.py")], capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0, out.stderr
+    rows = {}
+    for ln in out.stdout.splitlines()[1:]:
+        f = ln.split()
+        name, (sgpr, vgpr, sspill, vspill, scratch, occ) = " ".join(f[:-6]), (int(v) for v in f[-6:])
+        rows[name] = dict(sgpr=sgpr, vgpr=vgpr, sspill=sspill, vspill=vspill, scratch=scratch, occ=occ)
+    step = {k: v for k, v in rows.items() if "fused_step_kernel" in k or "persistent_steps_kernel" in k}
+    # three instantiations each: plain / force-only / peer, and plain / predicted / peer
+    assert sum("fused_step_kernel" in k for k in step) == 3 and sum("persistent_steps_kernel" in k for k in step) == 3, rows
+    for name, r in rows.items():
+        assert r["sspill"] == 0 and r["vspill"] == 0 and r["scratch"] == 0, (name, r)
+    for name, r in step.items():
+        assert r["vgpr"] <= 128 and r["occ"] >= 4, (name, r)
+        # scalar registers: 112 is the allocation band the grid sizing of the resident kernel assumes (saa_kernels.hip:
+        # persistent_max_blocks, MI355X_MICROARCH.md "Residency")
+        assert r["sgpr"] <= 112, (name, r)
