@@ -229,7 +229,7 @@ int saa_halo_gather(saa_solver *s, double *row_dev);
 int saa_halo_scatter(saa_solver *s, const double *row_dev);
 
 /* Whether saa_step / saa_step_predicted / saa_step_peer calls of >= 8 steps run through the resident multi-step
- * kernel (one cooperative launch per steps_per_launch steps, the partition's image kept in LDS between steps,
+ * kernel (one launch per steps_per_launch steps, the partition's image kept in LDS between steps,
  * DESIGN.md section 4) and how much LDS a workgroup of it holds.  capable = 0: the plan does not fit or the device
  * cannot keep all workgroups co-resident; every step is then one launch of the fused kernel. */
 int saa_resident_kernel_info(const saa_solver *s, int32_t *capable, int32_t *lds_bytes, int32_t *steps_per_launch);

@@ -383,9 +383,7 @@ void setup_persistent(saa_solver *s) {
   s->ps_capable = true;
 }
 
-// nsteps exchange-free steps in ONE cooperative launch; returns SAA_OK with *done = false when the resident kernel
-// does not apply (the caller then launches one fused kernel per step).
-// Exchange-free (or peer-exchange) steps through the resident kernel, in cooperative launches of at most
+// Exchange-free (or peer-exchange) steps through the resident kernel, in launches of at most
 // kPersistChunk steps; *n_done = how many of the nsteps were taken that way (0 when the resident kernel does not
 // apply, < nsteps if a launch was refused half-way: the caller takes the rest with one fused kernel per step).
 constexpr int32_t kPersistChunk = 1000;

@@ -94,7 +94,7 @@ void launch_fused_step_peer(const DeviceMesh &m, int threads, int lds_bytes, hip
                             const double *dn, double *d1, double *hist_row, const StepConsts &k,
                             const PeerMap *pm_dev, unsigned seq);
 void launch_peer_selftest(const PeerMap &pm, hipStream_t st, const double *own, double *out, unsigned seq);
-// Resident multi-step kernel (persistent_steps_kernel): ONE cooperative launch advances the partition by many time
+// Resident multi-step kernel (persistent_steps_kernel): ONE launch advances the partition by many time
 // steps.  Everything static (coordinates, mass, load, tags, connectivity) and the block's own displacements d^n,
 // d^(n-1) stay in LDS between steps; per step a workgroup only publishes its new displacements and re-reads those of
 // its halo nodes, as self-validating stamped entries (PeerEntry) - no flags, no grid barrier.

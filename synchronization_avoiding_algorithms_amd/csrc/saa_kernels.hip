@@ -599,7 +599,8 @@ __global__ void peer_selftest_kernel(PeerMap pm, const double *__restrict__ own,
 // first round of interior items, consumed at the end of that round - and recognise a value that has not arrived yet.
 // Two entry buffers alternate by step parity: an owner cannot overwrite what a reader still needs, because it cannot
 // get two steps ahead of a block it reads from.
-// All workgroups must be co-resident (cooperative launch); every wait is bounded (PersistArgs::timeout_ticks).
+// All workgroups must be co-resident (proved by a census launch at set-up); every wait is bounded
+// (PersistArgs::timeout_ticks).
 // ---------------------------------------------------------------------------------------------
 // Cross-workgroup traffic of the resident kernel uses agent-scope relaxed accesses only (global_load/store ... sc1:
 // served by / written through to the level all XCDs share) - no L2 write-back or invalidate inside the step loop
@@ -612,7 +613,7 @@ __host__ __device__ inline int persist_off_dn(int max_local, int fstride) { retu
 #endif
 constexpr int kPH = SAA_PERSIST_PRE;  // stamped halo entries per thread in flight during the first round
 // PREDICT: the predicted phase (table / history rows); a separate instantiation keeps its pointers out of the plain
-// kernel's scalar registers.  The argument block is read from device memory where it is needed for the same reason.
+// kernel's scalar registers.  The argument block is read field by field where it is needed for the same reason.
 // PEER: synchronised steps with the direct peer exchange (shared nodes pushed to / collected from the neighbour
 // ranks inside the step loop, like fused_step_kernel<.., PEER>).
 // The argument block travels BY VALUE in the kernel-argument segment (no separate kernel or copy to place it in device
