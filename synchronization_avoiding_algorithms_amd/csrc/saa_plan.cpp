@@ -217,6 +217,13 @@ struct PackStats {
   double read_mult = 0.0, atomic_mult = 0.0;  // sums of worst multiplicities
   int64_t read_cnt = 0, atomic_cnt = 0;
   int64_t by_construction = 0;  // items placed in clash-free halves by the pattern-class stage
+  void add(const PackStats &o) {
+    read_mult += o.read_mult;
+    atomic_mult += o.atomic_mult;
+    read_cnt += o.read_cnt;
+    atomic_cnt += o.atomic_cnt;
+    by_construction += o.by_construction;
+  }
 };
 
 // Re-order (and re-label) the items of one block part for the LDS traffic of the element phase (LDS image
@@ -503,6 +510,31 @@ int32_t reorder_for_lds(const uint16_t *items, int32_t n_items, int32_t n_owned,
   return done;
 }
 
+// pi[l] = rank of owned node l of a block when its nodes are sorted lexicographically with the axes in the q-th order
+void block_axis_order(const double *xyz, const int32_t *new_to_old, int32_t n_owned, int q, std::vector<uint16_t> &pi) {
+  static const int kPerm[6][3] = {{0, 1, 2}, {0, 2, 1}, {1, 0, 2}, {1, 2, 0}, {2, 0, 1}, {2, 1, 0}};
+  const int k0 = kPerm[q][0], k1 = kPerm[q][1], k2 = kPerm[q][2];
+  std::vector<int32_t> ord(n_owned);
+  std::iota(ord.begin(), ord.end(), 0);
+  std::sort(ord.begin(), ord.end(), [&](int32_t a, int32_t b) {
+    const double *pa = xyz + 3 * static_cast<int64_t>(new_to_old[a]), *pb = xyz + 3 * static_cast<int64_t>(new_to_old[b]);
+    if (pa[k0] != pb[k0]) return pa[k0] < pb[k0];
+    if (pa[k1] != pb[k1]) return pa[k1] < pb[k1];
+    if (pa[k2] != pb[k2]) return pa[k2] < pb[k2];
+    return a < b;
+  });
+  pi.resize(n_owned);
+  for (int32_t r = 0; r < n_owned; ++r) pi[ord[r]] = static_cast<uint16_t>(r);
+}
+// owned vertex slots of `n` items renamed through pi (halo slots keep their numbers)
+void relabel_owned(uint16_t *items, int32_t n, int32_t n_owned, const std::vector<uint16_t> &pi) {
+  for (int32_t i = 0; i < n; ++i) {
+    uint16_t *it = items + 8 * static_cast<size_t>(i);
+    for (int a = 0; a < (it[5] ? 5 : 4); ++a)
+      if (it[a] < n_owned) it[a] = pi[it[a]];
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 bool build_once(int32_t n_nodes, int32_t n_elems, const double *xyz, const int32_t *tets,
                 int32_t block_nodes, Plan &plan, std::string &err, bool &too_big, const int32_t *extra_work) {
@@ -661,9 +693,12 @@ bool build_once(int32_t n_nodes, int32_t n_elems, const double *xyz, const int32
   const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
   const unsigned n_thr = static_cast<unsigned>(std::min<int64_t>(hw, std::max<int32_t>(1, n_blocks / 8)));
   std::vector<PackStats> stats(n_thr);
+  std::vector<std::vector<uint16_t>> block_perm(n_blocks);  // non-empty: old -> new local index of the block's owned nodes
+  const char *alt_env = getenv("SAA_PLAN_FIXED_AXES");
+  const bool alt_axes = !(alt_env && alt_env[0] == '1');
   std::atomic<int32_t> next{0};
   auto work = [&](unsigned t) {
-    std::vector<uint16_t> items, part_a, part_b, loc_b;
+    std::vector<uint16_t> items, part_a, part_b, part_q, loc_b, trial, pi;
     std::vector<char> interior;
     for (int32_t b = next.fetch_add(1); b < n_blocks; b = next.fetch_add(1)) {
       const BlockDesc &d = plan.blocks[b];
@@ -689,7 +724,38 @@ bool build_once(int32_t n_nodes, int32_t n_elems, const double *xyz, const int32
         std::copy(&items[8 * static_cast<size_t>(i)], &items[8 * static_cast<size_t>(i)] + 8,
                   &out[8 * static_cast<size_t>(dst)]);
       }
-      const int32_t m_in = reorder_for_lds(out.data(), n_in, d.n_owned, pad, part_a, stats[t]);
+      PackStats st_in;
+      int32_t m_in = reorder_for_lds(out.data(), n_in, d.n_owned, pad, part_a, st_in);
+      // Which axis runs fastest inside the block decides how well its interior items pack: with L layers along the
+      // (outer, middle, inner) axes the lattice index is inner + L_in * (middle + L_mid * outer), and the translates of an
+      // element pair reach all 32 bank residues only if those strides are not all multiples of 8 - a 12 x 8 x 8-node box
+      // numbered (x, y, z) packs a quarter of its interior items clash-free, numbered (y, z, x) three quarters; ragged
+      // layers at the block faces decide the rest.  So: when the plan order does badly, the other five lexicographic
+      // orders of the owned nodes are tried on the interior items and the best one becomes the block's numbering.
+      if (alt_axes && n_in >= 256 && 10 * st_in.by_construction < 6 * n_in) {
+        int best_q = 0;
+        int64_t best_constr = st_in.by_construction;
+        std::vector<uint16_t> best_pi;
+        for (int q = 1; q < 6; ++q) {
+          block_axis_order(xyz, plan.new_to_old.data() + d.node_start, d.n_owned, q, pi);
+          trial.assign(out.begin(), out.begin() + 8 * static_cast<size_t>(n_in));
+          relabel_owned(trial.data(), n_in, d.n_owned, pi);
+          PackStats st_q;
+          (void)reorder_for_lds(trial.data(), n_in, d.n_owned, pad, part_q, st_q);
+          if (st_q.by_construction > best_constr + n_in / 10) {
+            best_constr = st_q.by_construction;
+            best_q = q;
+            best_pi = pi;
+          }
+        }
+        if (best_q != 0) {
+          relabel_owned(out.data(), ni, d.n_owned, best_pi);
+          st_in = PackStats();
+          m_in = reorder_for_lds(out.data(), n_in, d.n_owned, pad, part_a, st_in);
+          block_perm[b] = best_pi;
+        }
+      }
+      stats[t].add(st_in);
       const int32_t m_bd = reorder_for_lds(out.data() + 8 * static_cast<size_t>(n_in), ni - n_in, d.n_owned, pad,
                                            part_b, stats[t]);
       out = part_a;
@@ -704,6 +770,27 @@ bool build_once(int32_t n_nodes, int32_t n_elems, const double *xyz, const int32
     for (unsigned t = 1; t < n_thr; ++t) pool.emplace_back(work, t);
     work(0);
     for (auto &th : pool) th.join();
+  }
+  // blocks that changed their internal order: the numbering (and with it every halo list that names their nodes) follows
+  {
+    int32_t n_changed = 0;
+    for (int32_t b = 0; b < n_blocks; ++b) n_changed += !block_perm[b].empty();
+    if (getenv("SAA_PLAN_DEBUG")) fprintf(stderr, "plan: %d of %d blocks took another axis order\n", n_changed, n_blocks);
+    if (n_changed > 0) {
+      std::vector<int32_t> moved(plan.new_to_old);
+      for (int32_t b = 0; b < n_blocks; ++b) {
+        const std::vector<uint16_t> &pb = block_perm[b];
+        if (pb.empty()) continue;
+        const int32_t s0 = plan.blocks[b].node_start;
+        for (size_t l = 0; l < pb.size(); ++l) moved[s0 + pb[l]] = plan.new_to_old[s0 + l];
+      }
+      plan.new_to_old.swap(moved);
+      for (int32_t i = 0; i < n_nodes; ++i) plan.old_to_new[plan.new_to_old[i]] = i;
+      for (int32_t &g : plan.halo_ids) {
+        const int32_t ob = static_cast<int32_t>(std::upper_bound(block_start.begin(), block_start.end(), g) - block_start.begin()) - 1;
+        if (!block_perm[ob].empty()) g = block_start[ob] + block_perm[ob][g - block_start[ob]];
+      }
+    }
   }
   int64_t total_items = 0;
   for (int32_t b = 0; b < n_blocks; ++b) total_items += n_items[b];

@@ -41,7 +41,7 @@ struct Plan {
   std::vector<int32_t> new_to_old;  // internal node id -> caller's node id
   std::vector<int32_t> old_to_new;
   std::vector<BlockDesc> blocks;
-  std::vector<int32_t> halo_ids;    // internal node ids, per block sorted ascending
+  std::vector<int32_t> halo_ids;    // internal node ids, per block (sorted until blocks renumber their nodes, see block_perm)
   // Work items, 8 x uint16 each: block-local node indices (a, p, q, r, b), flag, 0, 0.  flag = 1: the two
   // face-adjacent tets A = (a; p,q,r) and B = (b; p,r,q) (5 node records and 5 force flushes for two
   // elements instead of 8 + 8); flag = 0: the single tet (a, p, q, r), b = p as a harmless dummy;
