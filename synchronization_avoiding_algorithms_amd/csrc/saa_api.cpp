@@ -416,7 +416,7 @@ int try_persistent_steps(saa_solver *s, int32_t nsteps, const double *table_dev,
     a.ramp_on = s->ramp;
     a.max_items = s->ps_max_items;
     a.table = table_dev;
-    a.hist = hist_dev ? hist_dev : (table_dev == nullptr && !peer ? s->ps_dbg : nullptr);
+    a.hist = hist_dev ? hist_dev : (table_dev == nullptr ? s->ps_dbg : nullptr);  // (ps_dbg: diagnostic builds only)
     a.table_row0 = table_row0 + *n_done;
     a.hist_row0 = hist_row0 + *n_done;
     a.width = 3 * static_cast<int64_t>(s->n_shared);

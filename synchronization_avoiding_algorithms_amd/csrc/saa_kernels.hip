@@ -729,18 +729,31 @@ __global__ void __launch_bounds__(SAA_LB) persistent_steps_kernel(DeviceMesh m, 
 #else
 #define PSTAMP(j)
 #endif
-  for (int s = 0; s < a.nsteps; ++s) {
-    PersistArgsPtr ah = ap;  // (PEER: opaque once per step, see the update phase)
+  // what the first half of a step needs of the argument block (PEER: re-read at the end of the step before, in front of
+  // its last barrier, through a pointer made opaque once per step - see the update phase)
+  int h_ramp_on;
+  unsigned h_step_base;
+  const PeerEntry *h_entries;
+  int64_t h_entry_stride;
+  auto load_head = [&]() {
+    PersistArgsPtr ah = ap;
     if (PEER) asm volatile("" : "+s"(ah));
-    const double ramp_now = ah->ramp_on ? (tn <= 1 ? tn : 1.0) : 1.0;  // commons.py:7-11 at the time of d^n
+    h_ramp_on = ah->ramp_on;
+    h_step_base = (unsigned)ah->step_base;
+    h_entries = ah->entries;
+    h_entry_stride = ah->entry_stride;
+  };
+  load_head();
+  for (int s = 0; s < a.nsteps; ++s) {
+    const double ramp_now = h_ramp_on ? (tn <= 1 ? tn : 1.0) : 1.0;  // commons.py:7-11 at the time of d^n
     if (!PEER) k.ramp = ramp_now;
     // Opaque copy of the thread index for the halo and update phases: whatever is derived from it is recomputed
     // every step.  Derived from `tid` the compiler hoists those per-thread constants (indices, addresses) out of
     // the step loop, keeps them alive through the item loops and spills.
     int ltid = tid;
     asm volatile("" : "+v"(ltid));
-    const unsigned want = (unsigned)(ah->step_base + s);  // stamp of d^(n+s), written by its owner in step s-1
-    const PeerEntry *ein = ah->entries + (int64_t)(s & 1) * ah->entry_stride;
+    const unsigned want = h_step_base + (unsigned)s;  // stamp of d^(n+s), written by its owner in step s-1
+    const PeerEntry *ein = h_entries + (int64_t)(s & 1) * h_entry_stride;
     // ---- 1. first round: interior items; the halo displacements are requested half-way through it (late enough
     //         for the neighbours' stores of the previous step to have landed, early enough to arrive by its end) --
     unsigned long long hlo[kPH], hhi[kPH];
@@ -840,6 +853,17 @@ __global__ void __launch_bounds__(SAA_LB) persistent_steps_kernel(DeviceMesh m, 
       k.dt = kp->dt; k.dt2 = kp->dt2; k.half_dt = kp->half_dt; k.alpha = kp->alpha; k.half_alpha = kp->half_alpha;
       k.ramp = ramp_now;
     }
+    // PEER: so is the range of this block's shared nodes in the peer map - a chain of three dependent scalar loads that
+    // every wave of every block would otherwise sit out between the barrier and its first dof (0.4 us per step)
+    const PeerMap *pm = nullptr;
+    int sh0 = 0, n_sh3 = 0;
+    unsigned pseq = 0;
+    if (PEER) {
+      pm = aq->peer;
+      pseq = aq->peer_seq_base + (unsigned)s + 1u;  // the host keeps a launch clear of the wrap to 0 ("never written")
+      sh0 = pm->blk_off[pblock];
+      n_sh3 = 3 * (pm->blk_off[pblock + 1] - sh0);
+    }
     lds_barrier();
     PSTAMP(5)
     asm volatile("" : "+v"(ltid));
@@ -858,13 +882,7 @@ __global__ void __launch_bounds__(SAA_LB) persistent_steps_kernel(DeviceMesh m, 
     };
     // PEER: partial forces of this block's shared nodes leave for the neighbour ranks first; their values are
     // collected after the update of the other nodes (the xGMI flight time hides under it)
-    int sh0 = 0, n_sh3 = 0;
-    unsigned pseq = 0;
     if (PEER) {
-      const PeerMap *pm = aq->peer;
-      pseq = aq->peer_seq_base + (unsigned)s + 1u;  // the host keeps a launch clear of the wrap to 0 ("never written")
-      sh0 = pm->blk_off[pblock];
-      n_sh3 = 3 * (pm->blk_off[pblock + 1] - sh0);
       for (int j = ltid; j < n_sh3; j += nt) {
         const int q = sh0 + j / 3, c = j % 3;
         const PeerPushRec r = pm->push_rec[q];
@@ -890,7 +908,6 @@ __global__ void __launch_bounds__(SAA_LB) persistent_steps_kernel(DeviceMesh m, 
       commit(i, n, c, u, v);
     }
     if (PEER) {
-      const PeerMap *pm = aq->peer;
       for (int j = ltid; j < n_sh3; j += nt) {
         const int q = sh0 + j / 3, c = j % 3;
         const PeerRecvRec r = pm->recv_rec[q];
@@ -905,6 +922,7 @@ __global__ void __launch_bounds__(SAA_LB) persistent_steps_kernel(DeviceMesh m, 
     }
     tn = tn + k.dt;  // Data_prepare.py:235
     PSTAMP(6)
+    if (PEER) load_head();
     lds_barrier();
     PSTAMP(7)
   }

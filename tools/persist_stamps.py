@@ -14,27 +14,34 @@ use_diag_library(["-DSAA_PERSIST_STAMPS"])  # diagnostic build of the library; t
 from bench import build_rank_solver  # noqa: E402
 from synchronization_avoiding_algorithms_amd.mesh import structured_beam  # noqa: E402
 
-# usage: persist_stamps.py [n [parts rank]]   (parts > 1: the x-slab partition `rank` of `parts`, exchange-free steps)
+# usage: persist_stamps.py [n [parts rank [peer]]]   (parts > 1: the x-slab partition `rank` of `parts`; exchange-free steps,
+#                                                      or - "peer" - steps through the peer exchange with loop-back)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 19
 parts = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 prank = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+peer = len(sys.argv) > 4 and sys.argv[4] == "peer"
 steps = 1000
 mesh = structured_beam(n)
 sol, lay, _, _ = build_rank_solver(mesh, parts, prank, 0)
 st = sol.plan_stats()
 waves = st["n_blocks"] * st["threads"] // 64
-dbg = torch.zeros(8 * waves, dtype=torch.float64, device="cuda")  # reinterpreted as uint64 by the kernel
+# reinterpreted as uint64 by the kernel; in peer mode the same buffer first receives the history rows of the shared dofs
+dbg = torch.zeros(max(8 * waves, steps * 3 * len(lay.shared_local) if peer else 0), dtype=torch.float64, device="cuda")
+step = sol.step
+if peer:
+    sol.peer_attach_loopback(2)
+    step = sol.step_peer
 import ctypes as C
 from synchronization_avoiding_algorithms_amd import _lib
 lib = _lib.load()
 lib.saa_debug_set_stamp_buffer.restype = C.c_int
-sol.step(200)
+step(200)
 sol.synchronize()
 _lib.check(lib.saa_debug_set_stamp_buffer(sol._h, C.c_void_p(dbg.data_ptr())))
-sol.step(steps)   # one launch of `steps` steps: the counts are per launch
+step(steps)   # one launch of `steps` steps: the counts are per launch
 sol.synchronize()
 _lib.check(lib.saa_debug_set_stamp_buffer(sol._h, None))
-t = dbg.cpu().numpy().view(np.uint64).reshape(waves, 8).astype(np.float64) / steps
+t = dbg[:8 * waves].cpu().numpy().view(np.uint64).reshape(waves, 8).astype(np.float64) / steps
 names = ["round 1 (interior items, halo fetch issued)", "-", "settle halo -> LDS", "barrier (halo)",
          "other interior + boundary items", "barrier (slowest wave)", "update", "barrier (end of step)"]
 tot = t.sum(axis=1)
@@ -42,5 +49,13 @@ print(f"n={n} plan {st}")
 print(f"shader-clock cycles per step per wave, median total {np.median(tot):.0f}")
 for j, nm in enumerate(names):
     print(f"  {nm:34s} median {np.median(t[:, j]):8.0f}  p90 {np.percentile(t[:, j], 90):8.0f}  max {t[:, j].max():8.0f}")
-ms = sol.time_steps(1000)
-print(f"stamped build: {ms:.3f} us/step")
+# per workgroup (16 waves each): which blocks are slow in the update phase (shared nodes sit in the face blocks)
+wg = t.reshape(st["n_blocks"], -1, 8).mean(axis=1)
+order = np.argsort(wg[:, 6])
+print("  update phase per workgroup: min %.0f median %.0f max %.0f;  items phases (0+4): min %.0f median %.0f max %.0f" % (
+    wg[:, 6].min(), np.median(wg[:, 6]), wg[:, 6].max(), (wg[:, 0] + wg[:, 4]).min(), np.median(wg[:, 0] + wg[:, 4]),
+    (wg[:, 0] + wg[:, 4]).max()))
+print("  slowest update workgroups:", [(int(b), int(wg[b, 6]), int(wg[b, 0] + wg[b, 4])) for b in order[-5:]])
+if not peer:
+    ms = sol.time_steps(1000)
+    print(f"stamped build: {ms:.3f} us/step")

@@ -29,11 +29,15 @@ for world in ([int(a) for a in sys.argv[1:]] or (2, 4, 8)):
     for r in range(world):
         sol, lay, _, _ = build_rank_solver(mesh, world, r, 0)
         st, ri = sol.plan_stats(), sol.resident_kernel_info()
-        sol.step(1000)
-        plain = timed(sol.step, 3000)
+        # clocks settle over the first tens of milliseconds of load: warm both paths, then alternate them
         sol.peer_attach_loopback(2)
-        sol.step_peer(1000)
-        peer = timed(sol.step_peer, 3000)
+        sol.step_peer(20000)
+        sol.step(20000)
+        pe, pl = [], []
+        for _ in range(5):
+            pe.append(timed(sol.step_peer, 3000))
+            pl.append(timed(sol.step, 3000))
+        plain, peer = sorted(pl)[2], sorted(pe)[2]
         sol.synchronize()
         print(f"N={world} rank {r}: tets {len(lay.cells_local)} nodes {len(lay.nodes)} shared {len(lay.shared_local)} "
               f"blocks {st['n_blocks']} max_owned {st['max_owned']} max_local {st['max_local']} conflict "
