@@ -889,6 +889,9 @@ __global__ void __launch_bounds__(SAA_LB) persistent_steps_kernel(DeviceMesh m, 
         peer_push(pm, r, q, c, acc[3 * (r.info & 0xffff) + c], pseq);
       }
     }
+#ifdef SAA_PEER_EMULATE_LATENCY  // tools/peer_latency.py: nothing pushed now counts as visible before t_push + that many
+    const long long t_push = wall_clock64();  // ticks of the 100 MHz wall clock (a stand-in for xGMI's delivery time)
+#endif
     // (one dof at a time: requesting the operands of a lane's two or three dofs up front and interleaving their
     // division chains was measured - 9.35 against 8.95 us/step at 1M tets, the extra live registers cost more than the
     // exposed LDS round trips)
@@ -912,6 +915,9 @@ __global__ void __launch_bounds__(SAA_LB) persistent_steps_kernel(DeviceMesh m, 
         const int q = sh0 + j / 3, c = j % 3;
         const PeerRecvRec r = pm->recv_rec[q];
         const int n = pm->push_rec[q].info & 0xffff, i = 3 * n + c;
+#ifdef SAA_PEER_EMULATE_LATENCY
+        while (wall_clock64() - t_push < SAA_PEER_EMULATE_LATENCY) __builtin_amdgcn_s_sleep(1);
+#endif
         const double f = peer_collect(pm, r, q, c, acc[3 * n + c], pseq);
         const double u = rec[6 * n + 3 + c];
         double v = cd_update_dof(f, c == 0 ? 0.0 : fextl[n], massl[n], u, dnl[i], k);  // Dynamic_solver.py:26-32
