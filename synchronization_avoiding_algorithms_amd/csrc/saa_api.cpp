@@ -124,6 +124,7 @@ struct saa_solver {
   DevBuf<int32_t> ps_err;
   DevBuf<saa::PeerEntry> ps_entries;  // 2 x 3*n_nodes stamped displacements
   int32_t ps_lds = 0, ps_max_items = 0, ps_steps = 0;
+  int32_t ps_lds_peer = 0;  // LDS of the PEER variant: the image plus the block's push / receive records (0: does not fit)
   bool ps_capable = false;  // plan fits LDS and all workgroups can be co-resident
   bool ps_enabled = true;   // saa_set_resident_kernel
   // trajectory recorder (saa_set_recorder)
@@ -326,6 +327,33 @@ int check_persist_error(saa_solver *s) {
   return SAA_OK;
 }
 
+// Census: one launch of the very kernel (same variant, same registers, same LDS, same grid) in which every workgroup
+// checks in and waits for all the others - the proof of co-residency that the stamped waits of the step loop rely on.
+// 50 ms bound; a grid that does not fit keeps the one-launch-per-step kernel.
+bool persistent_census(saa_solver *s, int lds, int mode) {
+  const int32_t nb = static_cast<int32_t>(s->plan.blocks.size());
+  DevBuf<int32_t> counter;
+  bool ok = counter.upload(std::vector<int32_t>(1, 0)) == hipSuccess;
+  saa::PersistArgs a{};
+  a.census = counter.p;
+  a.err = s->ps_err.p;
+  a.timeout_ticks = 5000000;  // 50 ms of the 100 MHz wall clock
+  a.max_items = s->ps_max_items;
+  ok = ok && saa::launch_persistent_steps(s->mesh, s->threads, lds, s->stream, s->consts, a, mode) == hipSuccess;
+  ok = ok && hipStreamSynchronize(s->stream) == hipSuccess;
+  int32_t e = 1, seen = 0;
+  ok = ok && hipMemcpy(&e, s->ps_err.p, sizeof(e), hipMemcpyDeviceToHost) == hipSuccess &&
+       hipMemcpy(&seen, counter.p, sizeof(seen), hipMemcpyDeviceToHost) == hipSuccess;
+  counter.release();
+  if (!ok || e != 0 || seen != nb) {
+    (void)hipGetLastError();
+    const int32_t zero = 0;
+    (void)hipMemcpy(s->ps_err.p, &zero, sizeof(zero), hipMemcpyHostToDevice);
+    return false;
+  }
+  return true;
+}
+
 // Entry buffers and capacity check of the resident kernel; failure only disables it.
 void setup_persistent(saa_solver *s) {
   s->ps_capable = false;
@@ -355,30 +383,9 @@ void setup_persistent(saa_solver *s) {
   s->ps_lds = lds;
   s->ps_max_items = max_items;
   s->ps_steps = 0;
-  // Census: one launch of the very kernel (same registers, same LDS, same grid) in which every workgroup checks in and
-  // waits for all the others - the proof of co-residency that the stamped waits of the step loop rely on.  50 ms bound;
-  // a grid that does not fit keeps the one-launch-per-step kernel.
-  {
-    DevBuf<int32_t> counter;
-    bool ok = counter.upload(std::vector<int32_t>(1, 0)) == hipSuccess;
-    saa::PersistArgs a{};
-    a.census = counter.p;
-    a.err = s->ps_err.p;
-    a.timeout_ticks = 5000000;  // 50 ms of the 100 MHz wall clock
-    a.max_items = max_items;
-    ok = ok && saa::launch_persistent_steps(s->mesh, s->threads, lds, s->stream, s->consts, a, 0) == hipSuccess;
-    ok = ok && hipStreamSynchronize(s->stream) == hipSuccess;
-    int32_t e = 1, seen = 0;
-    ok = ok && hipMemcpy(&e, s->ps_err.p, sizeof(e), hipMemcpyDeviceToHost) == hipSuccess &&
-         hipMemcpy(&seen, counter.p, sizeof(seen), hipMemcpyDeviceToHost) == hipSuccess;
-    counter.release();
-    if (!ok || e != 0 || seen != nb) {
-      (void)hipGetLastError();
-      const int32_t zero = 0;
-      (void)hipMemcpy(s->ps_err.p, &zero, sizeof(zero), hipMemcpyHostToDevice);
-      s->ps_entries.release();
-      return;
-    }
+  if (!persistent_census(s, lds, 0)) {
+    s->ps_entries.release();
+    return;
   }
   s->ps_capable = true;
 }
@@ -393,6 +400,7 @@ int try_persistent_steps(saa_solver *s, int32_t nsteps, const double *table_dev,
   *n_done = 0;
   if (s->det || !s->ps_capable || !s->ps_enabled || nsteps < kPersistMinSteps || !s->mesh.mass_node || !s->mesh.fext_yz)
     return SAA_OK;
+  if (peer && s->ps_lds_peer == 0) return SAA_OK;
   int32_t chunk = kPersistChunk;
   if (const char *env = std::getenv("SAA_PERSIST_CHUNK")) chunk = std::max(kPersistMinSteps, std::atoi(env));
   double timeout_s = 30.0;
@@ -423,6 +431,7 @@ int try_persistent_steps(saa_solver *s, int32_t nsteps, const double *table_dev,
     a.err = s->ps_err.p;
     a.timeout_ticks = static_cast<int64_t>(timeout_s * 1e8);
     a.peer = peer ? s->px_map.p : nullptr;
+    a.peer_rec_off = s->ps_lds;
     a.peer_seq_base = s->peer_seq;
     a.consts = s->consts;
     a.traj = s->rec_traj;
@@ -430,8 +439,8 @@ int try_persistent_steps(saa_solver *s, int32_t nsteps, const double *table_dev,
     a.traj_cols = s->rec_cols;
     a.step_index0 = s->rec_index;
     a.save_every = s->rec_every;
-    const hipError_t e = saa::launch_persistent_steps(s->mesh, s->threads, s->ps_lds, s->stream, s->consts, a,
-                                                      peer ? 2 : (table_dev != nullptr ? 1 : 0));
+    const hipError_t e = saa::launch_persistent_steps(s->mesh, s->threads, peer ? s->ps_lds_peer : s->ps_lds, s->stream,
+                                                      s->consts, a, peer ? 2 : (table_dev != nullptr ? 1 : 0));
     if (e != hipSuccess) {  // e.g. the device cannot hold all workgroups right now: keep the per-step path
       (void)hipGetLastError();
       s->ps_capable = false;
@@ -1127,6 +1136,16 @@ static int peer_attach_impl(saa_solver *s, int32_t rank, int32_t world, const ui
   pm.n_shared = nsh;
   HIP_TRY(s->px_map.upload(std::vector<saa::PeerMap>(1, pm)));
   s->peer_seq = 0;
+  // resident PEER kernel: every block keeps its push / receive records (16 bytes each per shared node) behind its LDS
+  // image; the larger workgroup has to pass the census again
+  s->ps_lds_peer = 0;
+  if (s->ps_capable) {
+    int32_t max_sh = 0;
+    for (size_t b = 0; b + 1 < blk_off.size(); ++b) max_sh = std::max(max_sh, blk_off[b + 1] - blk_off[b]);
+    const int lds = s->ps_lds + 32 * max_sh;
+    if (lds <= 160 * 1024 && saa::configure_persistent_peer(lds) == hipSuccess && persistent_census(s, lds, 2))
+      s->ps_lds_peer = lds;
+  }
   s->peer_ready = true;
   return SAA_OK;
 }

@@ -113,6 +113,7 @@ struct PersistArgs {
   int32_t *err;             // set to 1 when a wait timed out
   int64_t timeout_ticks;
   const PeerMap *peer;      // device copy of the peer map (synchronised steps with the peer exchange), or nullptr
+  int32_t peer_rec_off;     // PEER: byte offset in the LDS image of the block's copy of its push / receive records
   uint32_t peer_seq_base;   // sequence number of the last exchange before this launch
   // trajectory recorder (saa_set_recorder): d^(n+1) of step index i goes to column i / save_every of a row-major
   // (3*n_nodes, n_cols) matrix in the CALLER's dof order whenever i % save_every == 0 (Data_prepare.py:238-240)
@@ -130,6 +131,8 @@ void launch_record_column(int n_nodes, const int32_t *new_to_old, hipStream_t st
                           int64_t n_cols, int64_t col);
 // LDS bytes the resident kernel needs for this plan (0 = it cannot hold it).
 int persistent_lds_bytes(int max_local, int max_owned, int max_items, int max_halo);
+// Dynamic-LDS limit of the PEER variant (its image is followed by the block's peer records).
+hipError_t configure_persistent_peer(int lds_bytes);
 // How many workgroups of the resident kernel can be co-resident on the device (0 on error).
 int persistent_max_blocks(int device, int threads, int lds_bytes);
 // Launches the resident kernel; `a` travels by value in the kernel-argument segment.

@@ -716,6 +716,18 @@ __global__ void __launch_bounds__(SAA_LB) persistent_steps_kernel(DeviceMesh m, 
   }
   if (tid == 0 && n_halo3 == 0) hgl[0] = 0;  // the clamped prefetch below reads index 0 even without a halo
   for (int e = tid; e < bd.n_elem; e += nt) connl[e] = m.conn[bd.elem_off + e];
+  if (PEER) {
+    // the block's push / receive records (static; one pair per shared node it owns) behind the image: the shared nodes
+    // are a serial tail of a face block's step, and two dependent global loads less in it shorten every block's step
+    const PeerMap *pm0 = ap->peer;
+    const int s0 = pm0->blk_off[pblock], ns = pm0->blk_off[pblock + 1] - s0;
+    PeerPushRec *prl0 = reinterpret_cast<PeerPushRec *>(reinterpret_cast<char *>(lds) + ap->peer_rec_off);
+    PeerRecvRec *rrl0 = reinterpret_cast<PeerRecvRec *>(prl0 + ns);
+    for (int q = tid; q < ns; q += nt) {
+      prl0[q] = pm0->push_rec[s0 + q];
+      rrl0[q] = pm0->recv_rec[s0 + q];
+    }
+  }
   __syncthreads();
 
   const int n_pre = min(bd.n_interior, nt);  // items of the first round: they need no halo record
@@ -882,11 +894,17 @@ __global__ void __launch_bounds__(SAA_LB) persistent_steps_kernel(DeviceMesh m, 
     };
     // PEER: partial forces of this block's shared nodes leave for the neighbour ranks first; their values are
     // collected after the update of the other nodes (the xGMI flight time hides under it)
+    const PeerPushRec *prl = nullptr;
+    const PeerRecvRec *rrl = nullptr;
     if (PEER) {
+      int off = aq->peer_rec_off;  // (kept in a vector register like the other offsets of this variant)
+      asm volatile("" : "+v"(off));
+      prl = reinterpret_cast<const PeerPushRec *>(reinterpret_cast<const char *>(lds) + off);
+      rrl = reinterpret_cast<const PeerRecvRec *>(prl + n_sh3 / 3);
       for (int j = ltid; j < n_sh3; j += nt) {
-        const int q = sh0 + j / 3, c = j % 3;
-        const PeerPushRec r = pm->push_rec[q];
-        peer_push(pm, r, q, c, acc[3 * (r.info & 0xffff) + c], pseq);
+        const int c = j % 3;
+        const PeerPushRec r = prl[j / 3];
+        peer_push(pm, r, sh0 + j / 3, c, acc[3 * (r.info & 0xffff) + c], pseq);
       }
     }
 #ifdef SAA_PEER_EMULATE_LATENCY  // tools/peer_latency.py: nothing pushed now counts as visible before t_push + that many
@@ -913,8 +931,8 @@ __global__ void __launch_bounds__(SAA_LB) persistent_steps_kernel(DeviceMesh m, 
     if (PEER) {
       for (int j = ltid; j < n_sh3; j += nt) {
         const int q = sh0 + j / 3, c = j % 3;
-        const PeerRecvRec r = pm->recv_rec[q];
-        const int n = pm->push_rec[q].info & 0xffff, i = 3 * n + c;
+        const PeerRecvRec r = rrl[j / 3];
+        const int n = prl[j / 3].info & 0xffff, i = 3 * n + c;
 #ifdef SAA_PEER_EMULATE_LATENCY
         while (wall_clock64() - t_push < SAA_PEER_EMULATE_LATENCY) __builtin_amdgcn_s_sleep(1);
 #endif
@@ -1180,6 +1198,11 @@ int persistent_lds_bytes(int max_local, int max_owned, int max_items, int max_ha
   const long long bytes = 8ll * (persist_off_dn(max_local, fstride) + 3 * max_owned + 2 * max_owned) + 8ll * max_items +
                           4ll * max_owned + 12ll * max_halo + 16;
   return bytes <= 160 * 1024 ? (int)((bytes + 15) / 16 * 16) : 0;
+}
+
+hipError_t configure_persistent_peer(int lds_bytes) {
+  return hipFuncSetAttribute(reinterpret_cast<const void *>(&persistent_steps_kernel<false, true>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
 }
 
 int persistent_max_blocks(int device, int threads, int lds_bytes) {
