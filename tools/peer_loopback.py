@@ -52,17 +52,20 @@ def main():
     lay = make.lay
     print(f"rank {args.rank} of {args.gpus}: {len(lay.cells_local)} tets, {len(lay.nodes)} nodes, "
           f"{len(lay.shared_local)} shared nodes", flush=True)
-    plain.step(200)
-    base = plain.time_steps(args.steps) / args.steps * 1e3
+    plain.step(20000)  # clocks settle over the first tens of milliseconds of load
+    base = min(plain.time_steps(args.steps) for _ in range(3)) / args.steps * 1e3
     print(f"plain step (no exchange)        : {base:7.2f} us/step   plan {plain.plan_stats()}", flush=True)
     plain.close()
     for world in (() if args.plain_only else (2, 3)):
         sol = make()
         sol.peer_attach_loopback(world)
         ms = C.c_double()
-        _lib.check(lib.saa_debug_time_peer(sol._h, C.c_int32(200), C.byref(ms)))
-        _lib.check(lib.saa_debug_time_peer(sol._h, C.c_int32(args.steps), C.byref(ms)))
-        us = ms.value / args.steps * 1e3
+        _lib.check(lib.saa_debug_time_peer(sol._h, C.c_int32(20000), C.byref(ms)))
+        best = 1e300
+        for _ in range(3):
+            _lib.check(lib.saa_debug_time_peer(sol._h, C.c_int32(args.steps), C.byref(ms)))
+            best = min(best, ms.value)
+        us = best / args.steps * 1e3
         print(f"peer step, {world - 1} loopback neighbour(s): {us:7.2f} us/step   (+{us - base:.2f} us)", flush=True)
         sol.close()
 
