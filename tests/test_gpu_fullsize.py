@@ -58,6 +58,13 @@ def _operator_properties(sol, K, pts, rng):
     u = np.cross(np.array([3.0, -4.0, 5.0]), pts - pts.mean(axis=0))
     u *= 1e-2 / np.abs(u).max()
     assert np.abs(sol.internal_force(u.ravel())).max() < 1e-12 * scale
+    # K is linear and symmetric (size-independent properties of the assembled operator, Mat_construction.py:79-150):
+    # K(a d1 + b d2) = a K d1 + b K d2 and d2.K d1 = d1.K d2
+    d2 = rng.uniform(-1e-2, 1e-2, size=(sol.n_dof, 1))
+    f1, f2 = sol.internal_force(d), sol.internal_force(d2)
+    assert rel_l2(sol.internal_force(0.75 * d - 2.5 * d2), 0.75 * f1 - 2.5 * f2) < 1e-13
+    a, b = float(d2.ravel() @ f1.ravel()), float(d.ravel() @ f2.ravel())
+    assert abs(a - b) < 1e-12 * max(abs(a), abs(b))
     assert np.abs(K.dot(u.ravel())).max() < 1e-12 * scale  # the oracle agrees that it is a null vector
 
 
