@@ -153,3 +153,45 @@ def test_config3_middle_slab_of_the_8gpu_partition_through_the_peer_exchange():
         got[name] = g0
     assert rel_l2(got["resident"], got["fused"]) < 1e-11
     sol.close()
+
+
+def test_momentum_balance_of_the_free_one_million_tet_beam():
+    """A size-independent property of the update (Tools/Dynamic_solver.py:13-32) that needs no oracle: without Dirichlet
+    nodes the internal forces sum to zero (translation invariance of K), so for every step and component
+        sum_nodes [ m (d1 - 2 d0 + dn) / dt^2 + alpha m (d1 - dn) / (2 dt) ] = ramp(tn) * sum_nodes F
+    - checked on the columns the trajectory recorder takes out of one launch of the resident kernel."""
+    import torch
+    import synchronization_avoiding_algorithms_amd as saa
+    from synchronization_avoiding_algorithms_amd import fem_setup as fs
+    from synchronization_avoiding_algorithms_amd.mesh import structured_beam
+
+    mesh = structured_beam(19)
+    lmd, mu = fs.lame(E, NU)
+    lay, _ = fs.build_rank_layout(mesh.tets, np.zeros(len(mesh.tets), dtype=np.int64), 0, 1, len(mesh.points),
+                                  np.zeros(0, dtype=np.int64))
+    l_M, F, _ = fs.rank_fields(mesh.points, mesh.tets, lay, RHO, FZ)
+    dt = fs.cfl_dt(mesh.points, mesh.tets, E, NU, RHO, GAMMA)
+    sol = saa.HipExplicitSolver(mesh.points[lay.nodes], lay.cells_local, l_M, F, np.zeros(0, dtype=np.int32), lmd, mu, dt, ALPHA)
+    assert sol.resident_kernel_info()["capable"]
+    rng = np.random.default_rng(3)
+    d0 = rng.uniform(-1e-4, 1e-4, size=(sol.n_dof, 1))
+    dn = d0 + rng.uniform(-1e-6, 1e-6, size=(sol.n_dof, 1))
+    t0 = 0.4
+    sol.set_state(d0, dn, t0)
+    n_cols = 12
+    traj = torch.zeros((sol.n_dof, n_cols), dtype=torch.float64, device="cuda")
+    sol.set_recorder(traj, save_every=1, next_step_index=0)
+    sol.step(n_cols)  # one launch of the resident kernel
+    torch.cuda.synchronize()
+    cols = [dn.ravel(), d0.ravel()] + [traj[:, j].cpu().numpy() for j in range(n_cols)]
+    m, f = np.asarray(l_M).ravel(), np.asarray(F).ravel()
+    tn = t0
+    for j in range(n_cols):
+        a, b, c = cols[j], cols[j + 1], cols[j + 2]  # d^(n-1), d^n, d^(n+1)
+        lhs = m * (c - 2 * b + a) / dt ** 2 + ALPHA * m * (c - a) / (2 * dt)
+        for comp in range(3):
+            want = min(tn, 1.0) * f[comp::3].sum()
+            scale = np.abs(m[comp::3] * (c - 2 * b + a)[comp::3] / dt ** 2).sum()
+            assert abs(lhs[comp::3].sum() - want) < 1e-9 * scale, (j, comp)
+        tn = tn + dt
+    sol.close()
