@@ -195,3 +195,59 @@ def test_momentum_balance_of_the_free_one_million_tet_beam():
             assert abs(lhs[comp::3].sum() - want) < 1e-9 * scale, (j, comp)
         tn = tn + dt
     sol.close()
+
+
+def test_eight_million_tets_on_one_gpu_properties_of_the_fused_plan():
+    """The cache-exceeding point of the bench (`--refine 38`: 8 230 800 tets on one GPU, 2048 blocks of 512 threads, the
+    one-launch-per-step kernel) has no oracle run of its size; the same oracle-free properties as above hold for it:
+    rigid modes give no force, K is linear and symmetric, and every step of the free beam balances momentum."""
+    import torch
+    import synchronization_avoiding_algorithms_amd as saa
+    from synchronization_avoiding_algorithms_amd import fem_setup as fs
+    from synchronization_avoiding_algorithms_amd.mesh import structured_beam
+
+    mesh = structured_beam(38)
+    assert len(mesh.tets) == 8230800
+    lmd, mu = fs.lame(E, NU)
+    lay, _ = fs.build_rank_layout(mesh.tets, np.zeros(len(mesh.tets), dtype=np.int64), 0, 1, len(mesh.points),
+                                  np.zeros(0, dtype=np.int64))
+    l_M, F, _ = fs.rank_fields(mesh.points, mesh.tets, lay, RHO, FZ)
+    dt = fs.cfl_dt(mesh.points, mesh.tets, E, NU, RHO, GAMMA)
+    sol = saa.HipExplicitSolver(mesh.points[lay.nodes], lay.cells_local, l_M, F, np.zeros(0, dtype=np.int32), lmd, mu, dt, ALPHA)
+    st = sol.plan_stats()
+    assert st["n_blocks"] == 2048 and st["threads"] == 512 and not sol.resident_kernel_info()["capable"]
+    pts = mesh.points[lay.nodes]
+    rng = np.random.default_rng(38)
+    d = rng.uniform(-1e-2, 1e-2, size=(sol.n_dof, 1))
+    d2 = rng.uniform(-1e-2, 1e-2, size=(sol.n_dof, 1))
+    f1, f2 = sol.internal_force(d), sol.internal_force(d2)
+    scale = np.abs(f1).max()
+    assert np.abs(sol.internal_force(np.tile([1.0e-2, -0.5e-2, 0.25e-2], sol.n_nodes))).max() < 1e-12 * scale
+    u = np.cross(np.array([3.0, -4.0, 5.0]), pts - pts.mean(axis=0))
+    u *= 1e-2 / np.abs(u).max()
+    assert np.abs(sol.internal_force(u.ravel())).max() < 1e-12 * scale
+    assert rel_l2(sol.internal_force(0.75 * d - 2.5 * d2), 0.75 * f1 - 2.5 * f2) < 1e-13
+    a, b = float(d2.ravel() @ f1.ravel()), float(d.ravel() @ f2.ravel())
+    assert abs(a - b) < 1e-12 * max(abs(a), abs(b))
+    assert abs(f1.sum()) < 1e-9 * np.abs(f1).sum()  # internal forces of a free body sum to zero
+
+    d0 = rng.uniform(-1e-4, 1e-4, size=(sol.n_dof, 1))
+    dn = d0 + rng.uniform(-1e-6, 1e-6, size=(sol.n_dof, 1))
+    t0 = 0.4
+    sol.set_state(d0, dn, t0)
+    n_cols = 10
+    traj = torch.zeros((sol.n_dof, n_cols), dtype=torch.float64, device="cuda")
+    sol.set_recorder(traj, save_every=1, next_step_index=0)
+    sol.step(n_cols)
+    torch.cuda.synchronize()
+    cols = [dn.ravel(), d0.ravel()] + [traj[:, j].cpu().numpy() for j in range(n_cols)]
+    m, f = np.asarray(l_M).ravel(), np.asarray(F).ravel()
+    tn = t0
+    for j in range(n_cols):
+        p, q, r = cols[j], cols[j + 1], cols[j + 2]
+        lhs = m * (r - 2 * q + p) / dt ** 2 + ALPHA * m * (r - p) / (2 * dt)
+        for comp in range(3):
+            want = min(tn, 1.0) * f[comp::3].sum()
+            assert abs(lhs[comp::3].sum() - want) < 1e-9 * np.abs(m[comp::3] * (r - 2 * q + p)[comp::3] / dt ** 2).sum(), (j, comp)
+        tn = tn + dt
+    sol.close()
