@@ -147,6 +147,7 @@ struct saa_solver {
   DevBuf<int64_t> px_pstride, px_recv;
   DevBuf<saa::PeerPushRec> px_push_rec;
   DevBuf<saa::PeerRecvRec> px_recv_rec;
+  DevBuf<saa::PeerSecondRec> px_second_rec;
   DevBuf<saa::PeerMap> px_map;  // device copy of `peer` (the step kernel reads it from memory)
   DevBuf<unsigned long long> px_holders;
   DevBuf<double> px_own, px_test;
@@ -181,7 +182,7 @@ struct saa_solver {
     if (peer_mem) (void)hipFree(peer_mem);
     peer_mem = nullptr;
     px_blk_off.release(); px_node.release(); px_sidx.release(); px_nb_off.release(); px_err.release();
-    px_dst.release(); px_pstride.release(); px_recv.release(); px_push_rec.release(); px_recv_rec.release(); px_map.release(); px_holders.release(); px_own.release(); px_test.release();
+    px_dst.release(); px_pstride.release(); px_recv.release(); px_push_rec.release(); px_recv_rec.release(); px_second_rec.release(); px_map.release(); px_holders.release(); px_own.release(); px_test.release();
   }
 };
 
@@ -1074,12 +1075,20 @@ static int peer_attach_impl(saa_solver *s, int32_t rank, int32_t world, const ui
   nb_off[nsh] = static_cast<int32_t>(push_dst.size());
   std::vector<saa::PeerPushRec> push_rec(std::max<int32_t>(nsh, 1));
   std::vector<saa::PeerRecvRec> recv_rec(std::max<int32_t>(nsh, 1));
+  std::vector<saa::PeerSecondRec> second_rec(std::max<int32_t>(nsh, 1), saa::PeerSecondRec{nullptr, 0, 0});
   for (size_t b = 0; b < s->plan.blocks.size(); ++b)
     for (int32_t q = blk_off[b]; q < blk_off[b + 1]; ++q) {
+      if (nbs[q].size() >= 2) {
+        const Nb &g = nbs[q][1];
+        if (g.pstride > INT32_MAX || g.recv > INT32_MAX) return fail(SAA_E_CAPACITY, "saa_peer_attach: inbox too large");
+        second_rec[q] = {g.dst, static_cast<int32_t>(g.pstride), static_cast<int32_t>(g.recv)};
+      }
       const Nb f = nbs[q].empty() ? Nb{rank, nullptr, 0, 0} : nbs[q].front();
       if (f.pstride > INT32_MAX || f.recv > INT32_MAX) return fail(SAA_E_CAPACITY, "saa_peer_attach: inbox too large");
+      const bool highest = (holders[q] >> rank) == 1ull;
       push_rec[q] = {f.dst, static_cast<int32_t>(f.pstride),
-                     (node[q] - s->plan.blocks[b].node_start) | (static_cast<int32_t>(nbs[q].size()) << 16)};
+                     (node[q] - s->plan.blocks[b].node_start) | (static_cast<int32_t>(nbs[q].size()) << 16) |
+                         (highest ? saa::kPeerInfoHighest : 0)};
       recv_rec[q] = {holders[q], static_cast<int32_t>(f.recv), sidx[q]};
     }
   if (push_dst.empty()) {  // keep the device arrays non-null
@@ -1110,6 +1119,7 @@ static int peer_attach_impl(saa_solver *s, int32_t rank, int32_t world, const ui
   HIP_TRY(s->px_recv.upload(recv_idx));
   HIP_TRY(s->px_push_rec.upload(push_rec));
   HIP_TRY(s->px_recv_rec.upload(recv_rec));
+  HIP_TRY(s->px_second_rec.upload(second_rec));
   HIP_TRY(s->px_holders.upload(holders));
   HIP_TRY(s->px_err.upload(std::vector<int32_t>(1, 0)));
   HIP_TRY(s->px_own.upload(own));
@@ -1121,6 +1131,7 @@ static int peer_attach_impl(saa_solver *s, int32_t rank, int32_t world, const ui
   pm.holders = s->px_holders.p;
   pm.push_rec = s->px_push_rec.p;
   pm.recv_rec = s->px_recv_rec.p;
+  pm.second_rec = s->px_second_rec.p;
   pm.nb_off = s->px_nb_off.p;
   pm.push_dst = s->px_dst.p;
   pm.push_pstride = s->px_pstride.p;
@@ -1136,13 +1147,13 @@ static int peer_attach_impl(saa_solver *s, int32_t rank, int32_t world, const ui
   pm.n_shared = nsh;
   HIP_TRY(s->px_map.upload(std::vector<saa::PeerMap>(1, pm)));
   s->peer_seq = 0;
-  // resident PEER kernel: every block keeps its push / receive records (16 bytes each per shared node) behind its LDS
-  // image; the larger workgroup has to pass the census again
+  // resident PEER kernel: every block keeps its push / receive / second-neighbour records (16 bytes each per shared node)
+  // behind its LDS image; the larger workgroup has to pass the census again
   s->ps_lds_peer = 0;
   if (s->ps_capable) {
     int32_t max_sh = 0;
     for (size_t b = 0; b + 1 < blk_off.size(); ++b) max_sh = std::max(max_sh, blk_off[b + 1] - blk_off[b]);
-    const int lds = s->ps_lds + 32 * max_sh;
+    const int lds = s->ps_lds + 48 * max_sh;
     if (lds <= 160 * 1024 && saa::configure_persistent_peer(lds) == hipSuccess && persistent_census(s, lds, 2))
       s->ps_lds_peer = lds;
   }

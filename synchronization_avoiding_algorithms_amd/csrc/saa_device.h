@@ -65,16 +65,26 @@ struct PeerEntry {
 struct PeerPushRec {
   PeerEntry *dst0;     // first neighbour: remote address of component 0, parity 0
   int32_t pstride0;    // entries between that neighbour's parity-0 and parity-1 inbox
-  int32_t info;        // bits 0..15 node index inside its plan block, bits 16.. number of neighbours
+  int32_t info;        // bits 0..15 node index inside its plan block, bits 16..23 number of neighbours, bit 30: this
+                       // rank is the highest-ranked holder of the node (kPeerInfoHighest)
 };
+constexpr int32_t kPeerInfoHighest = 1 << 30;
 struct PeerRecvRec {
   unsigned long long holders;  // bit p set: rank p holds that node
   int32_t recv0;               // first neighbour: entry index of component 0 in this rank's parity-0 inbox
   int32_t sidx;                // position in the caller's shared list
 };
+// A node's SECOND other holder (the edges of a k-way partition: three ranks on a node), for the resident kernel, which
+// keeps these records in LDS; four or more holders take the generic lists.
+struct PeerSecondRec {
+  PeerEntry *dst1;   // second neighbour: remote address of component 0, parity 0 (nullptr: none)
+  int32_t pstride1;  // entries between that neighbour's parity-0 and parity-1 inbox
+  int32_t recv1;     // entry index of component 0 in this rank's parity-0 inbox
+};
 struct PeerMap {
   const PeerPushRec *push_rec;        // (n_shared)
   const PeerRecvRec *recv_rec;        // (n_shared)
+  const PeerSecondRec *second_rec;    // (n_shared)
   const int32_t *blk_off;             // (n_blocks + 1) plan block -> range in the node-sorted shared list
   const int32_t *node;                // (n_shared) internal node id, ascending
   const int32_t *sidx;                // (n_shared) position in the caller's shared list

@@ -286,7 +286,7 @@ __device__ __forceinline__ void peer_store(PeerEntry *d, double f, unsigned seq)
 // ~30 scalar registers for the whole tail of the step, and the step kernels have none to spare)
 __device__ __forceinline__ void peer_push(const PeerMap *pm, const PeerPushRec &r, int q, int c, double f, unsigned seq) {
   const int64_t par = seq & 1u;
-  const int n_nb = r.info >> 16;
+  const int n_nb = (r.info >> 16) & 0xff;
   if (n_nb > 0) peer_store(r.dst0 + par * r.pstride0 + c, f, seq);
   if (n_nb > 1) {  // node held by three or more ranks
     const int e0 = pm->nb_off[q];
@@ -723,9 +723,11 @@ __global__ void __launch_bounds__(SAA_LB) persistent_steps_kernel(DeviceMesh m, 
     const int s0 = pm0->blk_off[pblock], ns = pm0->blk_off[pblock + 1] - s0;
     PeerPushRec *prl0 = reinterpret_cast<PeerPushRec *>(reinterpret_cast<char *>(lds) + ap->peer_rec_off);
     PeerRecvRec *rrl0 = reinterpret_cast<PeerRecvRec *>(prl0 + ns);
+    PeerSecondRec *srl0 = reinterpret_cast<PeerSecondRec *>(rrl0 + ns);
     for (int q = tid; q < ns; q += nt) {
       prl0[q] = pm0->push_rec[s0 + q];
       rrl0[q] = pm0->recv_rec[s0 + q];
+      srl0[q] = pm0->second_rec[s0 + q];
     }
   }
   __syncthreads();
@@ -896,15 +898,25 @@ __global__ void __launch_bounds__(SAA_LB) persistent_steps_kernel(DeviceMesh m, 
     // collected after the update of the other nodes (the xGMI flight time hides under it)
     const PeerPushRec *prl = nullptr;
     const PeerRecvRec *rrl = nullptr;
+    const PeerSecondRec *srl = nullptr;
     if (PEER) {
       int off = aq->peer_rec_off;  // (kept in a vector register like the other offsets of this variant)
       asm volatile("" : "+v"(off));
       prl = reinterpret_cast<const PeerPushRec *>(reinterpret_cast<const char *>(lds) + off);
       rrl = reinterpret_cast<const PeerRecvRec *>(prl + n_sh3 / 3);
+      srl = reinterpret_cast<const PeerSecondRec *>(rrl + n_sh3 / 3);
       for (int j = ltid; j < n_sh3; j += nt) {
         const int c = j % 3;
         const PeerPushRec r = prl[j / 3];
-        peer_push(pm, r, sh0 + j / 3, c, acc[3 * (r.info & 0xffff) + c], pseq);
+        const double f = acc[3 * (r.info & 0xffff) + c];
+        if (((r.info >> 16) & 0xff) == 2) {  // three holders: both neighbours from the LDS records
+          const PeerSecondRec r2 = srl[j / 3];
+          const int64_t par = pseq & 1u;
+          peer_store(r.dst0 + par * r.pstride0 + c, f, pseq);
+          peer_store(r2.dst1 + par * r2.pstride1 + c, f, pseq);
+        } else {
+          peer_push(pm, r, sh0 + j / 3, c, f, pseq);
+        }
       }
     }
 #ifdef SAA_PEER_EMULATE_LATENCY  // tools/peer_latency.py: nothing pushed now counts as visible before t_push + that many
@@ -932,11 +944,24 @@ __global__ void __launch_bounds__(SAA_LB) persistent_steps_kernel(DeviceMesh m, 
       for (int j = ltid; j < n_sh3; j += nt) {
         const int q = sh0 + j / 3, c = j % 3;
         const PeerRecvRec r = rrl[j / 3];
-        const int n = prl[j / 3].info & 0xffff, i = 3 * n + c;
+        const int info = prl[j / 3].info, n = info & 0xffff, i = 3 * n + c;
 #ifdef SAA_PEER_EMULATE_LATENCY
         while (wall_clock64() - t_push < SAA_PEER_EMULATE_LATENCY) __builtin_amdgcn_s_sleep(1);
 #endif
-        const double f = peer_collect(pm, r, q, c, acc[3 * n + c], pseq);
+        double f;
+        if (((info >> 16) & 0xff) == 2) {
+          // three holders: the two neighbours' values, summed with this rank's own in RANK order like peer_collect does
+          // (the neighbour entries are in rank order; a + b == b + a)
+          int recv1 = srl[j / 3].recv1;
+          asm volatile("" : "+v"(recv1));
+          const PeerEntry *in = pm->inbox + (int64_t)(pseq & 1u) * pm->parity_stride + c;
+          const double own = acc[3 * n + c];
+          const double va = peer_wait(pm, in + r.recv0, pseq);
+          const double vb = peer_wait(pm, in + recv1, pseq);
+          f = (info & kPeerInfoHighest) ? (va + vb) + own : (own + va) + vb;
+        } else {
+          f = peer_collect(pm, r, q, c, acc[3 * n + c], pseq);
+        }
         const double u = rec[6 * n + 3 + c];
         double v = cd_update_dof(f, c == 0 ? 0.0 : fextl[n], massl[n], u, dnl[i], k);  // Dynamic_solver.py:26-32
         if (tagl[n] & (1 << c)) v = 0.0;
