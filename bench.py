@@ -10,12 +10,20 @@ with the peer exchange in use the RCCL variant is measured too and reported as `
 BASELINE.json configs[2] (the ~1M-tet beam, one partition); N > 1 keeps ~1M tets per GPU (weak scaling; N = 8 is
 configs[3], the ~8M-tet beam in 8 slabs; `sync_avoiding` = configs[4]).  Rank 0 prints ONE JSON line.
 
+The run has ONE deadline (`--budget-s`, counted from the start of the job) and every leg a budget inside it; the
+headline is measured first, and once it exists the line is printed no matter what the later legs do - a leg that does
+not fit is skipped, a leg that hangs is cut off by the watchdog, which prints the line with that leg marked and leaves
+with a non-zero status (`legs`, `leg_seconds`).
+
 Extra objects on the N = 1 line:
-  roofline      algorithmic bytes/step (16*Ne + 216*Nn) / HIP-event time of the fused
-                kernel's stream, against the 8 TB/s HBM peak of MI355X_MICROARCH.md.
-  cpu_baseline  the CPU oracle ("port": SciPy CSR K.dot + the NumPy update, the reference's own per-step
-                operations) timed on one host core on a bounded sample; the same sample is stepped on the GPU
-                and compared (parity.rel_l2).
+  roofline      contract figure: algorithmic bytes/step (16*Ne + 216*Nn) / HIP-event time on the
+                kernel's own stream, against the 8 TB/s HBM peak of MI355X_MICROARCH.md - an EQUIVALENT bandwidth (what a
+                kernel re-reading the partition every step would have to sustain); next to it what the kernel really
+                moves (`traffic`, `hbm_measured`) and what really bounds it (`onchip`: VALU / LDS / barrier shares and
+                fp64 rate from the committed PMC passes and stamps of the same kernel and mesh).
+  cpu_baseline  the CPU oracle ("port": SciPy CSR K.dot + the NumPy update, the reference's own per-step operations)
+                timed on the SAME mesh on one host core and on min(8, cores) cores (one process per x-slab); the GPU
+                steps the same mesh for the parity figure (parity.rel_l2).
 """
 from __future__ import annotations
 
@@ -23,6 +31,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -32,8 +41,150 @@ sys.path.insert(0, REPO)
 
 E, NU, RHO, FZ, ALPHA, GAMMA = 1e6, 0.3, 1.0, 0.5, 0.5, 0.9
 HBM_PEAK = 8.0e12  # B/s, MI355X_MICROARCH.md "HBM3E peak BW"
+# fp64 vector peak: half the FP32 vector rate of MI355X_MICROARCH.md (157.3 TFLOP/s = 256 CUs x 4 SIMDs x 64 flop/clk x
+# 2.4 GHz; v_fma_f64 issues at half that rate) - AMD's datasheet figure for MI355X FP64 vector
+FP64_VECTOR_PEAK = 78.6e12
 # mesh refinement per GPU count: 150*n^3 tets ~ N * 1.03M
 N_FOR_GPUS = {1: 19, 2: 24, 3: 27, 4: 30, 5: 32, 6: 34, 7: 36, 8: 38}
+ONCHIP_SUMMARY = os.path.join(REPO, "profiles", "r03_onchip_summary.json")
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# deadline, legs, watchdog
+# ---------------------------------------------------------------------------------------------------------------
+def job_start_time():
+    """Epoch seconds at which this JOB started: the start of the oldest ancestor process that is still part of it
+    (``python bench.py --gpus N`` -> ``torch.distributed.run`` -> this rank), so that all ranks count the budget from
+    the same instant and a launcher's slow first ``import torch`` on a fresh box is inside the budget, not in front of it."""
+    env = os.environ.get("SAA_BENCH_T0")
+    if env:
+        return float(env)
+    now = time.time()
+
+    def part_of_job(argv):
+        # `python bench.py ...` or `python -m torch.distributed.run ... bench.py ...` - not a shell, a test runner or a
+        # profiler that merely carries "bench.py" somewhere in its command line
+        if not argv or not os.path.basename(argv[0]).startswith("python"):
+            return False
+        rest = argv[1:]
+        if len(rest) >= 2 and rest[0] == "-m":
+            return rest[1] == "torch.distributed.run" and any(os.path.basename(a) == "bench.py" for a in rest[2:])
+        return bool(rest) and os.path.basename(rest[0]) == "bench.py"
+
+    try:
+        with open("/proc/uptime") as fh:
+            boot = now - float(fh.read().split()[0])
+        tick = os.sysconf("SC_CLK_TCK")
+        pid, t0 = os.getpid(), now
+        for _ in range(4):
+            with open(f"/proc/{pid}/stat") as fh:
+                f = fh.read().rsplit(")", 1)[1].split()
+            with open(f"/proc/{pid}/cmdline", "rb") as fh:
+                argv = [a.decode(errors="replace") for a in fh.read().split(b"\0") if a]
+            if pid != os.getpid() and not part_of_job(argv):
+                break
+            t0 = min(t0, boot + int(f[19]) / tick)  # field 22: start time in clock ticks since boot
+            pid = int(f[1])                          # field 4: parent
+            if pid <= 1:
+                break
+        return t0
+    except (OSError, ValueError, IndexError):
+        return now
+
+
+class Legs:
+    """Book-keeping of the run's legs and the watchdog that guarantees the line.  ``line`` is what rank 0 prints."""
+
+    def __init__(self, t0, budget_s, rank):
+        self.t0, self.budget, self.rank = t0, budget_s, rank
+        self.line = None                    # the JSON object, once the headline exists
+        self.status, self.seconds = {}, {}
+        self.lock = threading.Lock()
+        self._cut = None                    # (deadline, leg) of the leg currently running under a cut-off
+        self._done = threading.Event()
+        self._started = {}
+        threading.Thread(target=self._watch, daemon=True).start()
+
+    def left(self):
+        return self.t0 + self.budget - time.time()
+
+    def begin(self, leg, limit_s=None):
+        """Start of a leg; ``limit_s``: the watchdog cuts the run off (line printed, exit 3) if the leg lasts longer."""
+        with self.lock:
+            self._started[leg] = time.time()
+            self.status[leg] = "running"
+            self._cut = (time.time() + limit_s, leg) if limit_s is not None else None
+
+    def end(self, leg, status="done"):
+        with self.lock:
+            self.seconds[leg] = round(time.time() - self._started.get(leg, time.time()), 3)
+            self.status[leg] = status
+            self._cut = None
+
+    def skip(self, leg, why):
+        with self.lock:
+            self.status[leg] = f"skipped: {why}"
+
+    def emit(self, final):
+        """Print the line (rank 0).  Called by the main thread at the end, or by the watchdog when time is up."""
+        with self.lock:
+            if self.line is not None and self.rank == 0:
+                out = dict(self.line)
+                out["legs"] = dict(self.status)
+                out["leg_seconds"] = dict(self.seconds, total=round(time.time() - self.t0, 3))
+                out["budget_s"] = self.budget
+                print(json.dumps(out), flush=True)
+            if final:
+                self._done.set()
+
+    def _watch(self):
+        margin = 8.0  # seconds before the deadline at which the line is printed
+        while not self._done.wait(0.5):
+            now = time.time()
+            with self.lock:
+                cut = self._cut
+            why = None
+            if cut is not None and now > cut[0]:
+                why = f"timed out ({cut[1]})"
+                with self.lock:
+                    self.status[cut[1]] = "unfinished: leg time limit"
+            elif now > self.t0 + self.budget - margin:
+                why = "deadline"
+                with self.lock:
+                    for leg, st in self.status.items():
+                        if st == "running":
+                            self.status[leg] = "unfinished: deadline"
+            if why is None:
+                continue
+            if self.line is None and self.rank == 0:
+                sys.stderr.write(f"bench: {why} before the headline was measured; legs: {self.status}\n")
+            self.emit(final=False)
+            sys.stderr.flush()
+            if self.rank != 0:
+                time.sleep(1.5)  # rank 0's line first
+            os._exit(3)  # non-zero: a hang or an overrun must be seen (the line above is still valid)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+def bench_mesh(n, kind):
+    """The bench's mesh: the structured ``25n x n x n`` Kuhn-tet beam, or (``--mesh jittered``) the same beam with every
+    interior node moved by up to 20 % of the cube edge and nodes and elements renumbered at random - no lattice
+    structure for the LDS packing to find, like the reference's own Gmsh mesh (Mesh_info/beam_coarse.vtk)."""
+    from synchronization_avoiding_algorithms_amd.mesh import Mesh, structured_beam
+
+    mesh = structured_beam(n)
+    if kind == "structured":
+        return mesh
+    rng = np.random.default_rng(0)
+    pts = mesh.points.copy()
+    h = 1.0 / n
+    inner = np.all((pts > 1e-9) & (pts < np.array([25.0, 1.0, 1.0]) - 1e-9), axis=1)
+    pts[inner] += rng.uniform(-0.2 * h, 0.2 * h, size=(int(inner.sum()), 3))
+    perm = rng.permutation(len(pts))          # new id of old node i
+    new_pts = np.empty_like(pts)
+    new_pts[perm] = pts
+    tets = perm[mesh.tets][rng.permutation(len(mesh.tets))]
+    return Mesh(new_pts, {"tetra": tets, "triangle": perm[mesh.triangles]})
 
 
 def build_rank_solver(mesh, n_parts, rank, device, block_nodes=0, threads=0):
@@ -54,66 +205,69 @@ def build_rank_solver(mesh, n_parts, rank, device, block_nodes=0, threads=0):
     return sol, lay, gshared, dt
 
 
-def measured_copy_bandwidth(n_bytes=1 << 30, reps=10):
-    """Device-to-device copy rate (read + write bytes per second) of this GPU: the practical HBM ceiling
-    SURVEY.md section 8(d) asks to report next to the nominal 8 TB/s."""
-    import torch
+def measured_copy_bandwidth(device=0, n_bytes=1 << 30, reps=10):
+    """Device-to-device copy rate (read + written bytes per second) of this GPU, by the library's own 16-byte-per-lane
+    copy kernel (``saa_device_copy_bandwidth``; MI355X_MICROARCH.md quotes 6.29 TB/s for such a copy): the practical
+    HBM ceiling SURVEY.md section 8(d) asks to report next to the nominal 8 TB/s."""
+    import ctypes as C
 
-    a = torch.empty(n_bytes // 8, dtype=torch.float64, device="cuda").normal_()
-    b = torch.empty_like(a)
-    b.copy_(a)
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        b.copy_(a)
-    e1.record()
-    torch.cuda.synchronize()
-    return 2.0 * n_bytes * reps / (e0.elapsed_time(e1) * 1e-3)
+    from synchronization_avoiding_algorithms_amd import _lib
+
+    bw = C.c_double()
+    _lib.check(_lib.load().saa_device_copy_bandwidth(int(device), int(n_bytes), int(reps), C.byref(bw)))
+    return bw.value
 
 
-def cpu_baseline_and_parity(sample_n=10, steps=6000, parity_steps=3000):
+def cpu_baseline_and_parity(n, one_core_steps=300, mp_steps=1000, legs=None):
     """Oracle (CPU port of the reference's per-step operations: SciPy CSR ``K.dot`` + the NumPy update expression) timed
-    on a bounded sample, on ONE host core (SciPy's SpMV is single-threaded) and on P = min(8, cores) cores the way the
-    reference runs distributed (one process per x-slab, shared-node forces summed every step:
-    ``oracle/cpu_baseline_mp.py``); the GPU steps the same sample for the parity figure."""
+    on the bench's own mesh: on ONE host core (SciPy's SpMV is single-threaded) and on P = min(8, cores) cores the way
+    the reference runs distributed (one process per x-slab, shared-node forces summed every step:
+    ``oracle/cpu_baseline_mp.py``).  The matrix is assembled like the reference assembles it (element matrices added
+    in element order, ``fem_oracle.assemble_local_stiffness_blocked``).  The GPU steps the same mesh from the same
+    state for the parity figure.  With little time left (``legs.left()``) the step counts shrink, and below ~100 s the
+    150k-tet beam stands in - the line says which mesh was timed and why."""
     from oracle import cpu_baseline_mp
     from oracle import fem_oracle as fo
     from synchronization_avoiding_algorithms_amd.mesh import structured_beam
 
-    mesh = structured_beam(sample_n)
-    ranks, dt, _, _ = fo.setup_problem(mesh.points, mesh.tets, mesh.triangles, 1,
-                                       np.zeros(len(mesh.tets), dtype=int))
+    left = legs.left() if legs is not None else 1e9
+    fallback = None
+    if left < 100.0 and n > 10:  # (measured on the build host: 25 s of set-up + 45 ms per step at 1M tets on one core)
+        fallback = f"only {left:.0f} s of the budget were left: the 1M-tet set-up (~25 s) + steps did not fit"
+        n, one_core_steps, mp_steps = 10, 3000, 15000
+    mesh = structured_beam(n)
+    t_setup = time.perf_counter()
+    ranks, dt, _, _ = fo.setup_problem(mesh.points, mesh.tets, mesh.triangles, 1, np.zeros(len(mesh.tets), dtype=int))
+    t_setup = time.perf_counter() - t_setup
     rp = ranks[0]
     d0 = np.zeros((len(rp.local_dof), 1))
     dn = np.zeros_like(d0)
     tn = 0
     t0 = time.perf_counter()
-    snap = None
-    for i in range(steps):
+    for _ in range(one_core_steps):
         d1 = fo.explicit_step(rp.K, rp.F, rp.dirichlet, tn, dt, d0, dn, rp.l_M, ALPHA)
         dn, d0 = d0, d1
         tn = tn + dt
-        if i + 1 == parity_steps:
-            snap = d0
     cpu_s = time.perf_counter() - t0
     sol, lay, _, gdt = build_rank_solver(mesh, 1, 0, 0)
     assert gdt == dt and np.array_equal(lay.nodes, rp.nodes)
-    sol.step(parity_steps)
+    sol.step(one_core_steps)
     g0, _, _ = sol.get_state()
     sol.close()
-    rel = float(np.linalg.norm(g0 - snap) / np.linalg.norm(snap))
+    rel = float(np.linalg.norm(g0 - d0) / np.linalg.norm(d0))
     ne = len(mesh.tets)
-    what = f"synthetic beam n={sample_n} ({ne} tets, {len(mesh.points)} nodes)"
-    one = {"value": ne * steps / cpu_s, "unit": "element-updates/s", "cores": 1,
-           "sample": f"{what}, {steps} steps, scipy CSR K.dot + numpy update (oracle/fem_oracle.py), {cpu_s:.2f} s"}
+    what = f"synthetic beam n={n} ({ne} tets, {len(mesh.points)} nodes)"
+    one = {"value": ne * one_core_steps / cpu_s, "unit": "element-updates/s", "cores": 1,
+           "ms_per_step": 1e3 * cpu_s / one_core_steps,
+           "sample": f"{what}, {one_core_steps} steps, scipy CSR K.dot (nnz {rp.K.nnz}) + numpy update "
+                     f"(oracle/fem_oracle.py), {cpu_s:.2f} s after {t_setup:.1f} s of assembly"}
     cores = min(8, os.cpu_count() or 1)
     base = dict(one, kind="port")
     if cores > 1:
         try:
-            mp_steps = 5 * steps  # ~5-10 s of wall time on 8 cores
-            mp = cpu_baseline_mp.run(cores, sample_n, mp_steps)
+            mp = cpu_baseline_mp.run(cores, n, mp_steps)
             base = {"value": ne * mp_steps / mp["seconds"], "unit": "element-updates/s", "cores": cores, "kind": "port",
+                    "ms_per_step": 1e3 * mp["seconds"] / mp_steps,
                     "sample": f"{what} in {cores} x-slabs, one process per slab ({os.cpu_count()} host cores), {mp_steps} "
                               f"steps, per step scipy CSR K.dot + sum of the {mp['n_shared']} shared nodes' forces "
                               f"over the ranks in rank order (shared memory) + numpy update "
@@ -121,20 +275,28 @@ def cpu_baseline_and_parity(sample_n=10, steps=6000, parity_steps=3000):
                     "one_core": one}
         except Exception as e:  # noqa: BLE001 - the one-core figure is still a valid baseline
             base["multi_process_failed"] = str(e)[:200]
-    return (base, {"rel_l2": rel, "mesh": f"synthetic beam n={sample_n}", "steps": parity_steps, "tolerance": 1e-10})
+    if fallback:
+        base["fallback"] = fallback
+    return (base, {"rel_l2": rel, "mesh": what, "steps": one_core_steps, "tolerance": 1e-10,
+                   "against": "oracle (assembled CSR of the same mesh), from rest under the ramped load"})
 
 
 def preflight_main(world, rank, local_rank):
     """Child process of one rank (bench.py --preflight): a tiny partitioned problem stepped through the peer exchange
     on the real devices.  Exit code 0 = the direct xGMI path works here; anything else (including a crash of this
     process) makes the parent fall back to the RCCL all-reduce."""
+    hook = os.environ.get("SAA_BENCH_TEST_PREFLIGHT")  # tests only: a preflight that fails / never returns
+    if hook == "fail":
+        return 3
+    if hook == "hang":
+        time.sleep(3600)
     import torch
     import torch.distributed as dist
 
     import datetime
 
     torch.cuda.set_device(local_rank)
-    dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=90))  # a crashed peer must not park the others
+    dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=60))  # a crashed peer must not park the others
     from synchronization_avoiding_algorithms_amd.distributed import PartitionedSolver
     from synchronization_avoiding_algorithms_amd.mesh import slab_partition, structured_beam
 
@@ -154,30 +316,41 @@ def preflight_main(world, rank, local_rank):
     return 0 if all(flags) else 3
 
 
-def run_preflight(args, world):
-    """Runs preflight_main in a child process BEFORE this process touches the GPU; True iff it exited cleanly."""
+def run_preflight(args, world, limit_s):
+    """Runs preflight_main in a child process BEFORE this process touches the GPU; True iff it exited cleanly within
+    ``limit_s`` seconds (the child and whatever it started are killed otherwise)."""
+    import signal
     import subprocess
 
     env = dict(os.environ)
     env["MASTER_PORT"] = str(int(env.get("MASTER_PORT", "29500")) + 17)
     env.pop("TORCHELASTIC_USE_AGENT_STORE", None)  # the children's rank 0 hosts their own rendezvous store
     env["SAA_PEER_TIMEOUT_S"] = env.get("SAA_PEER_TIMEOUT_S", "20")
+    cmd = [sys.executable, os.path.abspath(__file__), "--preflight", "--gpus", str(world)]
+    if args.same_device:
+        cmd.append("--same-device")
     try:
-        cmd = [sys.executable, os.path.abspath(__file__), "--preflight", "--gpus", str(world)]
-        if args.same_device:
-            cmd.append("--same-device")
-        r = subprocess.run(cmd, env=env, timeout=420, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-        return r.returncode == 0
-    except Exception:  # noqa: BLE001 - timeout, spawn failure
+        proc = subprocess.Popen(cmd, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+    except OSError:
+        return False
+    try:
+        return proc.wait(timeout=max(1.0, limit_s)) == 0
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(proc.pid, signal.SIGKILL)
+        except OSError:
+            pass
+        proc.wait()
         return False
 
 
-def sync_avoiding_leg(part, args, rank, world, ne_total, fence):
+def sync_avoiding_leg(part, args, rank, world, ne_total, fence, train_seconds):
     """BASELINE.json configs[4] the way the reference's workflow produces it (README.md:33-38), all on the GPUs:
       1. ground truth  - the synchronised run from rest (Data_prepare.py:223-240), recording every rank's shared-dof
                          history (what Shared_extraction.py slices out) and the full state at the end of every window;
       2. training      - one LSTM per rank on ITS history (Model_training.py; training.train_on_history: windowing,
-                         [-1, 0] scaling, Adam with 0.998^epoch decay, HIP-graph optimiser step), for a bounded time;
+                         [-1, 0] scaling, Adam with 0.998^epoch decay, HIP-graph optimiser step): `--sa-train-epochs`
+                         epochs (0: the reference's schedule, until the rate reaches lr_min), at most `train_seconds`;
       3. sync-avoiding - the same simulation again (Online_predictor.py:251-318): n_past*filter_size synchronised
                          steps, then windows of n_future*filter_size steps in which the shared dofs come from the
                          rank's model and NO exchange is issued.  Timed: prediction + stepping of the windows.
@@ -211,11 +384,25 @@ def sync_avoiding_leg(part, args, rank, world, ne_total, fence):
         sol.get_state_device(snap, None)
         snaps.append(snap)
     fence()
-    # 2. one model per rank, trained on its own history
+    # 2. one model per rank, trained on its own history.  The epoch count is what decides the model (fixed seeds); the
+    #    time bound only protects the run's deadline.  Ranks sharing one GPU (rehearsals) train one after the other:
+    #    graph replays of two processes on one device get in each other's way.
+    epochs = None
+    if args.sa_train_epochs is not None:
+        epochs = args.sa_train_epochs if args.sa_train_epochs > 0 else None  # 0: Model_training.py:65
+        schedule = "fixed epoch count" if args.sa_train_epochs > 0 else "reference schedule (until lr_min)"
+    else:
+        epochs, schedule = 10 ** 9, "time-bounded"
     t0 = time.perf_counter()
-    with torch.enable_grad():
-        model, smax, smin, tl, vl = tr.train_on_history(truth, n_s, n_p, n_f, cut_off=1.0, seed=1234 + rank,
-                                                        hidden_size=hid, max_seconds=args.sa_train_seconds)
+    turns = world if args.same_device else 1
+    for turn in range(turns):
+        if turns == 1 or turn == rank:
+            with torch.enable_grad():
+                model, smax, smin, tl, vl = tr.train_on_history(truth, n_s, n_p, n_f, cut_off=1.0, seed=1234 + rank,
+                                                                hidden_size=hid, num_epochs=epochs,
+                                                                max_seconds=train_seconds / turns)
+        if turns > 1:
+            fence()
     fence()
     train_s = time.perf_counter() - t0
     groups = truth[::n_s].shape[0] - n_p - n_f + 1
@@ -245,6 +432,8 @@ def sync_avoiding_leg(part, args, rank, world, ne_total, fence):
     t = torch.tensor([elapsed, train_s], dtype=torch.float64, device="cuda")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed, train_s = (float(v) for v in t.tolist())
+    ep = torch.tensor([len(tl)], dtype=torch.int64, device="cuda")
+    dist.all_reduce(ep, op=dist.ReduceOp.MIN)
     finite = torch.tensor([float(torch.isfinite(hist[-1]).all())], device="cuda")
     dist.all_reduce(finite, op=dist.ReduceOp.MIN)
     return {"value": ne_total * windows * win / elapsed, "unit": "element-updates/s",
@@ -252,7 +441,9 @@ def sync_avoiding_leg(part, args, rank, world, ne_total, fence):
             "n_past": n_p, "n_future": n_f, "filter_size": n_s, "input_size_rank0": width,
             "synchronised_steps_before": start,
             "rel_l2_vs_synchronised": errs, "state_finite": bool(finite.item()),
-            "training": {"truth_steps": n_truth, "windows": int(groups), "epochs": len(tl), "seconds": train_s,
+            "training": {"truth_steps": n_truth, "windows": int(groups), "epochs": len(tl),
+                         "epochs_min_over_ranks": int(ep.item()), "schedule": schedule, "seconds": train_s,
+                         "seconds_allowed": train_seconds,
                          "train_mse_first_last": [tl[0], tl[-1]], "validation_mse_last": vl[-1], "hidden_size": hid},
             "note": f"after {start} synchronised steps every rank's LSTM (trained in this run on the synchronised "
                     f"history of its own shared dofs) predicts them for {win}-step windows; no collective inside a "
@@ -264,41 +455,71 @@ def launch_ranks(args):
     """``python bench.py --gpus N`` without a launcher: start the N ranks (one process per GPU) through
     ``torch.distributed.run`` - the reference's whole launch story is ``mpirun -np P python3 ...``
     (/root/reference README.md:33-38) - BEFORE this process makes any GPU call (it never does), relay rank 0's single
-    JSON line and exit non-zero if the ranks failed or printed no line."""
+    JSON line and exit non-zero if the ranks failed or printed no line.  The ranks keep the deadline themselves; this
+    parent ends their process group if they are still there 30 s after it."""
     import signal
     import socket
     import subprocess
 
+    t0 = job_start_time()
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
     env = dict(os.environ)
+    env["SAA_BENCH_T0"] = repr(t0)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL and the peer exchange need it on this image
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
     proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, start_new_session=True)
+
+    def reaper():
+        if proc.poll() is None:
+            try:
+                os.killpg(proc.pid, signal.SIGKILL)
+            except OSError:
+                pass
+
+    timer = threading.Timer(max(5.0, t0 + args.budget_s + 30.0 - time.time()), reaper)
+    timer.daemon = True
+    timer.start()
     line = None
     try:
         for ln in proc.stdout:  # rank 0's JSON line is the only thing the ranks write to stdout
             try:
                 if ln.lstrip().startswith("{") and "metric" in json.loads(ln):
                     line = ln.strip()
+                    print(line, flush=True)  # at once: whatever happens to the ranks later, the line is out
                     continue
             except ValueError:
                 pass
             sys.stderr.write(ln)
-        rc = proc.wait(timeout=args.launch_timeout)
-    except BaseException:  # timeout, Ctrl-C: end exactly the process group started above
-        try:
-            os.killpg(proc.pid, signal.SIGKILL)
-        except OSError:
-            pass
+        rc = proc.wait()
+    except BaseException:  # Ctrl-C: end exactly the process group started above
+        reaper()
         raise
-    if line is not None:
-        print(line, flush=True)
+    timer.cancel()
     if rc != 0 or line is None:
         raise SystemExit(rc if rc != 0 else 4)
+
+
+def onchip_block(key, us_per_step, ne_total):
+    """What bounds the kernel on the chip, from the committed PMC passes and in-kernel stamps of the same kernel and mesh
+    (profiles/r03_onchip_summary.json, written by tools/onchip_summary.py from rocprofv3 --pmc runs of this command)."""
+    try:
+        with open(ONCHIP_SUMMARY) as fh:
+            rec = json.load(fh)[key]
+    except (OSError, KeyError, ValueError):
+        return None
+    out = {k: rec[k] for k in ("valu_busy", "lds_busy", "lds_bank_conflict_share", "barrier_wait_share",
+                               "wave_wait_share", "wave_issue_stall_share") if k in rec}
+    if "fp64_flop_per_step" in rec:  # executed fp64 flops (element copies included), counted by the SQ
+        flops = rec["fp64_flop_per_step"] / (us_per_step * 1e-6)
+        out.update(fp64_flops_per_s=flops, frac_of_fp64_vector_peak=flops / FP64_VECTOR_PEAK,
+                   fp64_vector_peak=FP64_VECTOR_PEAK, fp64_flop_per_step=rec["fp64_flop_per_step"],
+                   fp64_flop_per_element_update=rec["fp64_flop_per_step"] / ne_total)
+    out["source"] = rec.get("source", "profiles/r03_onchip_summary.json")
+    return out
 
 
 def main():
@@ -307,16 +528,25 @@ def main():
     ap.add_argument("--steps", type=int, default=5000)
     ap.add_argument("--warmup", type=int, default=500)
     ap.add_argument("--refine", type=int, default=0, help="override mesh refinement n (25n x n x n cubes)")
+    ap.add_argument("--mesh", default="structured", choices=["structured", "jittered"],
+                    help="jittered: the same beam with moved nodes and random numbering (an unstructured mesh)")
     ap.add_argument("--block-nodes", type=int, default=0)
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--budget-s", type=float, default=420.0,
+                    help="deadline of the whole run in seconds from the start of the job; legs that do not fit are skipped, "
+                         "a leg that overruns is cut off (the line is printed either way once the headline exists)")
     ap.add_argument("--backend", default="nccl", help="process-group backend for N > 1 (nccl = RCCL)")
     ap.add_argument("--no-sync-avoiding", action="store_true", help="N > 1: skip the sync-avoiding-mode leg")
     ap.add_argument("--sa-windows", type=int, default=3, help="sync-avoiding leg: predicted windows that are timed")
     ap.add_argument("--sa-filter", type=int, default=150, help="sync-avoiding leg: filter_size n_s (Online_predictor.py:59)")
     ap.add_argument("--sa-truth-steps", type=int, default=30000,
                     help="sync-avoiding leg: synchronised steps recorded as training data")
-    ap.add_argument("--sa-train-seconds", type=float, default=60.0, help="sync-avoiding leg: training time bound per rank")
+    ap.add_argument("--sa-train-epochs", type=int, default=None,
+                    help="sync-avoiding leg: epochs of training per rank (0 = the reference's schedule, "
+                         "Model_training.py:65); default: as many as fit --sa-train-seconds")
+    ap.add_argument("--sa-train-seconds", type=float, default=60.0,
+                    help="sync-avoiding leg: cap on the training time per rank (further capped by the run's budget)")
     ap.add_argument("--no-rccl-leg", action="store_true",
                     help="N > 1: skip the extra measurement with the RCCL all-reduce when the peer exchange is in use")
     ap.add_argument("--torch-exchange", action="store_true",
@@ -329,7 +559,6 @@ def main():
     ap.add_argument("--preflight", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--min-timed-ms", type=float, default=50.0,
                     help="the timed call of --steps steps is repeated until the timed region lasts at least this long")
-    ap.add_argument("--launch-timeout", type=float, default=3000.0, help=argparse.SUPPRESS)
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -343,13 +572,18 @@ def main():
         local_rank = 0
     if args.preflight:
         raise SystemExit(preflight_main(world, rank, local_rank))
+    legs = Legs(job_start_time(), args.budget_s, rank)
     # N > 1: the direct peer exchange maps other processes' device memory - first use on this machine happens in a
     # child process, so that a fault there costs the child, not the benchmark (which then takes the RCCL all-reduce)
     exchange = "torch" if args.torch_exchange else args.exchange
     peer_ok = True
     if world > 1 and exchange == "auto" and (not args.same_device or os.environ.get("SAA_BENCH_FORCE_PREFLIGHT")):
-        peer_ok = run_preflight(args, world)
+        limit = min(90.0, 0.25 * max(legs.left(), 0.0))
+        legs.begin("preflight")
+        peer_ok = run_preflight(args, world, limit)
+        legs.end("preflight", "done" if peer_ok else f"failed or exceeded {limit:.0f} s: all-reduce instead of the peer exchange")
 
+    legs.begin("setup")
     import torch
     import torch.distributed as dist
 
@@ -361,7 +595,7 @@ def main():
             dist.init_process_group(args.backend)
 
     from synchronization_avoiding_algorithms_amd.distributed import PartitionedSolver
-    from synchronization_avoiding_algorithms_amd.mesh import slab_partition, structured_beam
+    from synchronization_avoiding_algorithms_amd.mesh import slab_partition
 
     if world > 1 and exchange == "auto":  # every rank takes the same transport
         flags = [None] * world
@@ -370,9 +604,10 @@ def main():
             exchange = "rccl"
     preflight = None if world == 1 or args.exchange != "auto" or args.torch_exchange else bool(peer_ok)
     n = args.refine or N_FOR_GPUS.get(world, int(round((world * 1028850 / 150.0) ** (1 / 3))))
-    mesh = structured_beam(n)
+    mesh = bench_mesh(n, args.mesh)
     ne_total, nn_total = len(mesh.tets), len(mesh.points)
     epart = slab_partition(mesh, world) if world > 1 else np.zeros(ne_total, dtype=np.int64)
+
     def fence():
         if world > 1:
             dist.barrier()
@@ -386,9 +621,9 @@ def main():
                                  threads=args.threads, exchange=how)
         part.step_synced(args.warmup)  # world == 1: plain steps; else one exchange of shared-node forces per step
         # The timed call is `part.step_synced(args.steps)`.  Which kernels that runs depends on the call length (calls
-        # of >= 8 steps take the resident kernel: one cooperative launch), so exactly that call is issued once more
-        # untimed - the first launch of a kernel pays code-object upload and cooperative-launch set-up - and its
-        # duration sizes the number of timed repetitions so that the timed region lasts >= --min-timed-ms.
+        # of >= 8 steps take the resident kernel), so exactly that call is issued once more untimed - the first launch
+        # of a kernel pays code-object upload - and its duration sizes the number of timed repetitions so that the
+        # timed region lasts >= --min-timed-ms.
         fence()
         t0 = time.perf_counter()
         part.step_synced(args.steps)
@@ -429,6 +664,8 @@ def main():
             elapsed = float(t.item())
         return part, elapsed, ok
 
+    legs.end("setup")
+    legs.begin("headline")
     part, elapsed, ok = build_and_time(exchange)
     timed_calls = build_and_time.calls
     retried = None
@@ -441,41 +678,60 @@ def main():
         raise SystemExit("bench: a wait inside the step kernels timed out")
     sol, gshared, dt = part.solver, part.global_shared, part.dt
 
-    # N > 1: the same partitions in sync-avoiding mode (BASELINE.json configs[4]; Online_predictor.py:251-318).
-    sync_avoiding = None
-    if world > 1 and not args.no_sync_avoiding:
-        sync_avoiding = sync_avoiding_leg(part, args, rank, world, ne_total, fence)
-
-    out = None
-    if rank == 0:
-        stats = sol.plan_stats()
-        out = {
-            "metric": "element_updates_per_s", "value": ne_total * args.steps / elapsed,
-            "unit": "element-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "timed_calls": timed_calls,
-            "ms_per_step": 1e3 * elapsed / args.steps, "steps_per_s": args.steps / elapsed,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
-            "data": "synthetic",
-            "config": {"workload": f"synthetic 25n x n x n Kuhn-tet cantilever n={n}: {ne_total} tets, "
-                                   f"{nn_total} nodes, {world} x-slab partition(s), fp64, E=1e6 nu=0.3 "
-                                   f"alpha=0.5 ramped body force, dt={dt:.6e}",
-                       "exchange": "none (1 partition)" if world == 1 else
-                                   {"peer": f"every step the fp64 forces of the shared nodes ({len(gshared)} in all) are "
-                                            "stored into the neighbour ranks' memory (HIP IPC, xGMI peer stores) and "
-                                            "summed in rank order (saa_step_peer); no collective",
-                                    "rccl": f"all-reduce of {3 * len(gshared)} fp64 shared-node forces every step, "
-                                            "ncclAllReduce issued from C++ (saa_step_synced)",
-                                    "torch": f"all-reduce of {3 * len(gshared)} fp64 shared-node forces every step, "
-                                             f"torch.distributed ({args.backend})"}[part.exchange],
-                       "plan": stats},
-        }
-    if rank == 0 and sync_avoiding is not None:
-        out["sync_avoiding"] = sync_avoiding
-    if rank == 0 and world > 1:
+    stats = sol.plan_stats()
+    out = {
+        "metric": "element_updates_per_s", "value": ne_total * args.steps / elapsed,
+        "unit": "element-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "timed_calls": timed_calls,
+        "ms_per_step": 1e3 * elapsed / args.steps, "steps_per_s": args.steps / elapsed,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": f"synthetic 25n x n x n Kuhn-tet cantilever n={n}"
+                               f"{' (nodes jittered, numbering shuffled)' if args.mesh == 'jittered' else ''}: "
+                               f"{ne_total} tets, {nn_total} nodes, {world} x-slab partition(s), fp64, E=1e6 nu=0.3 "
+                               f"alpha=0.5 ramped body force, dt={dt:.6e}",
+                   "exchange": "none (1 partition)" if world == 1 else
+                               {"peer": f"every step the fp64 forces of the shared nodes ({len(gshared)} in all) are "
+                                        "stored into the neighbour ranks' memory (HIP IPC, xGMI peer stores) and "
+                                        "summed in rank order (saa_step_peer); no collective",
+                                "rccl": f"all-reduce of {3 * len(gshared)} fp64 shared-node forces every step, "
+                                        "ncclAllReduce issued from C++ (saa_step_synced)",
+                                "torch": f"all-reduce of {3 * len(gshared)} fp64 shared-node forces every step, "
+                                         f"torch.distributed ({args.backend})"}[part.exchange],
+                   "plan": stats},
+    }
+    if world > 1:
         out["config"]["peer_preflight_rank0"] = preflight  # child-process trial of the peer exchange (None: not run)
         if retried:
             out["config"]["retried"] = retried
+    legs.end("headline")
+    with legs.lock:
+        legs.line = out  # from here on the line is printed whatever happens (watchdog)
+
+    def put(key, value):
+        with legs.lock:
+            out[key] = value
+
+    # N > 1: the same partitions in sync-avoiding mode (BASELINE.json configs[4]; Online_predictor.py:251-318).
+    rccl_wanted = (world > 1 and not args.no_rccl_leg and
+                   ((part.exchange == "peer" and args.backend == "nccl" and not args.same_device) or
+                    bool(os.environ.get("SAA_BENCH_FORCE_RCCL_LEG"))))
+    rccl_reserve = 60.0 if rccl_wanted else 0.0
+    if world > 1 and not args.no_sync_avoiding:
+        # what the leg needs besides training: the recorded run, the predictor's capture, the windows (~20 s at N = 8)
+        train_s = min(args.sa_train_seconds, legs.left() - rccl_reserve - 45.0)
+        t = torch.tensor([train_s], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)  # one decision for all ranks
+        train_s = float(t.item())
+        if train_s < 5.0:
+            legs.skip("sync_avoiding", f"{legs.left():.0f} s of the budget left")
+        else:
+            legs.begin("sync_avoiding")
+            put("sync_avoiding", sync_avoiding_leg(part, args, rank, world, ne_total, fence, train_s))
+            legs.end("sync_avoiding")
+
     if world == 1:
+        legs.begin("roofline")
         # roofline of the dominant (only) kernel: HIP events on the kernel's own stream
         # one launch of the resident kernel advances `spl` steps (one launch = spl * Ne element-updates); without it
         # (plan does not fit LDS / not all workgroups co-resident) one launch of the fused kernel is one step
@@ -485,74 +741,97 @@ def main():
         sol.time_steps(2 * spl if spl > 1 else 200)  # settle the clocks on this very path
         ms = sol.time_steps(launches * spl)
         b_alg = 16 * ne_total + 216 * nn_total
-        achieved = b_alg * launches * spl / (ms * 1e-3)
-        out["roofline"] = {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                           "frac": achieved / HBM_PEAK, "traffic": None,
-                           "kernel": "persistent_steps_kernel<false,false>" if spl > 1 else "fused_step_kernel<false>",
-                           "steps_per_launch": spl, "launches_timed": launches, "avg_launch_us": 1e3 * ms / launches,
-                           "us_per_step": 1e3 * ms / (launches * spl),
-                           "algorithmic_bytes_per_step": b_alg, "algorithmic_bytes_per_launch": b_alg * spl,
-                           "algorithmic_bytes_per_element_update": b_alg / ne_total,
-                           "note": "algorithmic bytes = SURVEY.md section 8(d) figure for a kernel that re-reads the "
-                                   "partition every step; the resident kernel keeps it in LDS and moves less "
-                                   "(see traffic)"}
+        dur_s = ms * 1e-3 / (launches * spl)  # per step
+        achieved = b_alg / dur_s
+        roof = {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK, "traffic": None,
+                "kernel": "persistent_steps_kernel<false,false>" if spl > 1 else "fused_step_kernel<false>",
+                "steps_per_launch": spl, "launches_timed": launches, "avg_launch_us": 1e3 * ms / launches,
+                "us_per_step": 1e6 * dur_s,
+                "algorithmic_bytes_per_step": b_alg, "algorithmic_bytes_per_launch": b_alg * spl,
+                "algorithmic_bytes_per_element_update": b_alg / ne_total,
+                "note": "achieved / frac are the CONTRACT figure: algorithmic bytes (SURVEY.md section 8(d): what a kernel "
+                        "that re-reads the partition every step must move) per second - an equivalent bandwidth, not the "
+                        "kernel's HBM traffic.  What it moves is `traffic` / `hbm_measured`; what bounds it is `onchip` "
+                        "(`effective_limiter`)."}
         # HBM traffic per launch from the committed PMC passes of this same kernel and mesh (tools/pmc_collect.sh:
         # rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes, nothing else enabled; KiB units; FETCH_SIZE
         # doubled: gfx950 counts 64 B per 128-B request, MI355X_MICROARCH.md "HBM").  Only for the meshes that were
         # profiled (n = 19 resident, n = 38 fused); otherwise null.
-        try:
-            with open(os.path.join(REPO, "profiles", "r02_pmc_summary.json")) as fh:
-                pmc = json.load(fh)
-            key = f"r02_resident{n}" if spl > 1 else f"r02_fused{n}"
-            fetch = pmc[f"{key}:FETCH_SIZE"]["mean_per_dispatch"]
-            write = pmc[f"{key}:WRITE_SIZE"]["mean_per_dispatch"]
-            out["roofline"]["traffic"] = (2.0 * fetch + write) * 1024.0
-            out["roofline"]["traffic_source"] = ("profiles/r02_pmc_summary.json (rocprofv3 --pmc, separate passes, "
-                                                 "launches of the same length)")
-        except (OSError, KeyError, ValueError):
-            pass
-        copy_bw = measured_copy_bandwidth()
-        out["roofline"]["measured_copy_GBps"] = copy_bw / 1e9
-        out["roofline"]["frac_of_measured_copy"] = achieved / copy_bw
-        if not args.no_cpu_baseline:
-            out["cpu_baseline"], out["parity"] = cpu_baseline_and_parity()
+        key = (f"resident{n}" if spl > 1 else f"fused{n}") + ("_jittered" if args.mesh == "jittered" else "")
+        for rnd in ("r03", "r02"):
+            try:
+                with open(os.path.join(REPO, "profiles", f"{rnd}_pmc_summary.json")) as fh:
+                    pmc = json.load(fh)
+                fetch = pmc[f"{rnd}_{key}:FETCH_SIZE"]["mean_per_dispatch"]
+                write = pmc[f"{rnd}_{key}:WRITE_SIZE"]["mean_per_dispatch"]
+            except (OSError, KeyError, ValueError):
+                continue
+            roof["traffic"] = (2.0 * fetch + write) * 1024.0
+            roof["traffic_source"] = (f"profiles/{rnd}_pmc_summary.json (rocprofv3 --pmc, separate passes, launches of "
+                                      "the same length)")
+            hbm = roof["traffic"] / (dur_s * spl)
+            roof["hbm_measured"] = {"GBps": hbm / 1e9, "frac_of_peak": hbm / HBM_PEAK,
+                                    "traffic_over_algorithmic": roof["traffic"] / (b_alg * spl)}
+            break
+        onchip = onchip_block(key, 1e6 * dur_s, ne_total)
+        if onchip is not None:
+            roof["onchip"] = onchip
+            roof["effective_limiter"] = ("on-chip: fp64 vector issue and the LDS pipe, each busy about two thirds of the "
+                                         "time, plus the barrier-separated phases that keep them from overlapping "
+                                         "(not HBM: see hbm_measured)")
+        copy_bw = measured_copy_bandwidth(local_rank)
+        roof["measured_copy_GBps"] = copy_bw / 1e9
+        roof["measured_copy_kernel"] = "saa_device_copy_bandwidth: 16 B per lane, 1 GiB -> 1 GiB, 10 launches"
+        roof["frac_of_measured_copy"] = achieved / copy_bw
+        put("roofline", roof)
+        legs.end("roofline")
+        if args.no_cpu_baseline:
+            legs.skip("cpu_baseline", "--no-cpu-baseline")
+        elif legs.left() < 45.0:
+            legs.skip("cpu_baseline", f"{legs.left():.0f} s of the budget left")
+        else:
+            legs.begin("cpu_baseline")
+            base, parity = cpu_baseline_and_parity(n if args.mesh == "structured" else 10, legs=legs)
+            put("cpu_baseline", base)
+            put("parity", parity)
+            legs.end("cpu_baseline")
     sol.close()
     # N > 1: BASELINE.json configs[3] names the RCCL all-reduce as the per-step exchange.  When `value` above was
     # measured with the peer exchange, the same partitions are stepped once more with ncclAllReduce issued from C++
     # (saa_step_synced) and reported next to it.
-    leg_ok = (args.backend == "nccl" and not args.same_device) or bool(os.environ.get("SAA_BENCH_FORCE_RCCL_LEG"))
-    if world > 1 and part.exchange == "peer" and leg_ok and not args.no_rccl_leg:
-        import threading
-
-        leg_done = threading.Event()
-
-        def watchdog():  # a hung collective must not cost the headline line: after 4 minutes print what has been
-            if not leg_done.wait(240):  # measured and leave with a NON-ZERO status, so that the hang is seen
-                if rank == 0:
-                    out["rccl_allreduce"] = {"value": None, "exchange": "timed out after 240 s"}
-                    print(json.dumps(out), flush=True)
-                os._exit(3)
-
-        threading.Thread(target=watchdog, daemon=True).start()
-        k_r, w_r = min(args.steps, 2000), min(args.warmup, 200)
-        args_steps, args_warmup = args.steps, args.warmup
-        args.steps, args.warmup = k_r, w_r
-        try:
-            part_r, elapsed_r, ok_r = build_and_time("rccl" if args.backend == "nccl" else "torch")
-            how = part_r.exchange
-            part_r.close()
-        except Exception as e:  # noqa: BLE001 - reported, never fatal for the headline line
-            ok_r, how, elapsed_r = False, f"failed: {e}"[:200], float("nan")
-        args.steps, args.warmup = args_steps, args_warmup
-        if rank == 0:
-            out["rccl_allreduce"] = ({"value": ne_total * k_r / elapsed_r, "unit": "element-updates/s",
-                                      "ms_per_step": 1e3 * elapsed_r / k_r, "steps": k_r, "warmup": w_r, "exchange": how,
-                                      "note": "same partitions; shared-node forces summed by an all-reduce of "
-                                              f"{3 * len(gshared)} doubles every step instead of the peer exchange"}
-                                     if ok_r else {"value": None, "exchange": how})
-        leg_done.set()
-    if rank == 0:
-        print(json.dumps(out), flush=True)
+    if rccl_wanted:
+        limit = min(90.0, legs.left() - 12.0)
+        t = torch.tensor([limit], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        limit = float(t.item())
+        if limit < 20.0:
+            legs.skip("rccl_allreduce", f"{legs.left():.0f} s of the budget left")
+            put("rccl_allreduce", {"value": None, "exchange": "skipped: budget"})
+        else:
+            # a hung collective must not cost the headline line: past the limit the watchdog prints what has been
+            # measured and leaves with a NON-ZERO status, so that the hang is seen
+            put("rccl_allreduce", {"value": None, "exchange": f"timed out after {limit:.0f} s"})
+            legs.begin("rccl_allreduce", limit_s=limit)
+            if os.environ.get("SAA_BENCH_TEST_STALL_RCCL"):  # tests only: a collective that never returns
+                time.sleep(3600)
+            k_r, w_r = min(args.steps, 2000), min(args.warmup, 200)
+            args_steps, args_warmup = args.steps, args.warmup
+            args.steps, args.warmup = k_r, w_r
+            try:
+                part_r, elapsed_r, ok_r = build_and_time("rccl" if args.backend == "nccl" else "torch")
+                how = part_r.exchange
+                part_r.close()
+            except Exception as e:  # noqa: BLE001 - reported, never fatal for the headline line
+                ok_r, how, elapsed_r = False, f"failed: {e}"[:200], float("nan")
+            args.steps, args.warmup = args_steps, args_warmup
+            put("rccl_allreduce", ({"value": ne_total * k_r / elapsed_r, "unit": "element-updates/s",
+                                    "ms_per_step": 1e3 * elapsed_r / k_r, "steps": k_r, "warmup": w_r, "exchange": how,
+                                    "note": "same partitions; shared-node forces summed by an all-reduce of "
+                                            f"{3 * len(gshared)} doubles every step instead of the peer exchange"}
+                                   if ok_r else {"value": None, "exchange": how}))
+            legs.end("rccl_allreduce", "done" if ok_r else "failed")
+    legs.emit(final=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -30,8 +30,13 @@ def main():
     ap.add_argument("--out", default="/tmp/saa_run")
     ap.add_argument("--backend", default="nccl")
     ap.add_argument("--same-device", action="store_true")
+    ap.add_argument("--sequential-training", action="store_true",
+                    help="ranks sharing one GPU train one after the other (each with the graphed optimiser step) instead "
+                         "of at the same time with eager launches: what a full-schedule run on a one-GPU box wants")
     args = ap.parse_args()
-    if args.same_device:
+    if args.epochs <= 0:  # the reference's schedule: until the decayed rate reaches lr_min (Model_training.py:65)
+        args.epochs = None
+    if args.same_device and not args.sequential_training:
         # ranks sharing one GPU: graph replays of two processes on one device get in each other's way (2x slower than
         # eager launches); with one GPU per rank the graphed optimiser step is 3.7x faster and stays on
         os.environ.setdefault("SAA_TRAIN_GRAPH", "0")
@@ -63,9 +68,12 @@ def main():
         print(f"[rank 0] steps {args.steps}: data_prepare {t1 - t0:.1f} s; a single partition has no shared nodes - run "
               "with --nproc-per-node 2 (add --same-device --backend gloo on a one-GPU machine) for the sync-avoiding part")
         return
-    path, tl, vl = training.train_rank_model(args.out, rank, device=f"cuda:{local}", hidden_size=args.hidden_size,
-                                             filter_size=args.filter_size, num_epochs=args.epochs, seed=rank, verbose=True)
-    barrier()
+    for turn in range(world if args.sequential_training else 1):
+        if not args.sequential_training or turn == rank:
+            path, tl, vl = training.train_rank_model(args.out, rank, device=f"cuda:{local}", hidden_size=args.hidden_size,
+                                                     filter_size=args.filter_size, num_epochs=args.epochs, seed=rank,
+                                                     verbose=True)
+        barrier()
     t2 = time.time()
     _, modeled, _ = drivers.online_predictor(mesh, args.steps, 1, args.out, rank, world, device=local,
                                              filter_size=args.filter_size, hidden_size=args.hidden_size)
@@ -73,7 +81,13 @@ def main():
     i_cri = 20 * args.filter_size
     err_all = np.linalg.norm(modeled - truth) / np.linalg.norm(truth)
     err_pred = np.linalg.norm(modeled[:, i_cri:] - truth[:, i_cri:]) / np.linalg.norm(truth[:, i_cri:])
-    print(f"[rank {rank}] steps {args.steps}: data_prepare {t1 - t0:.1f} s, extraction+training ({args.epochs} epochs, "
+    # the field at the end of every predicted window (n_future * filter_size steps each, Online_predictor.py:284)
+    win = 20 * args.filter_size
+    ends = list(range(i_cri + win - 1, modeled.shape[1], win))
+    per_window = [float(np.linalg.norm(modeled[:, e] - truth[:, e]) / np.linalg.norm(truth[:, e])) for e in ends]
+    print(f"[rank {rank}] rel-L2 of the rank's displacement field at the end of predicted window 1.."
+          f"{len(per_window)}: " + " ".join(f"{v:.2e}" for v in per_window), flush=True)
+    print(f"[rank {rank}] steps {args.steps}: data_prepare {t1 - t0:.1f} s, extraction+training ({len(tl)} epochs, "
           f"final train/val MSE {tl[-1]:.3e}/{vl[-1]:.3e}) {t2 - t1:.1f} s, online_predictor {t3 - t2:.1f} s; "
           f"rel-L2(sync-avoiding vs synchronised) = {err_all:.3e} overall, {err_pred:.3e} over the predicted phase",
           flush=True)

@@ -249,6 +249,12 @@ int saa_set_deterministic(saa_solver *s, int32_t enable);
 /* Blocks until all work enqueued for this handle has finished. */
 int saa_synchronize(saa_solver *s);
 
+/* Measurement aid for bench.py: device-to-device copy rate of this GPU - bytes read + bytes written per second by a
+ * 16-byte-per-lane copy kernel over two buffers of n_bytes each, `reps` timed launches - the practical HBM ceiling that
+ * SURVEY.md section 8(d) asks to be reported next to the nominal peak.  No counterpart in the reference (which has no
+ * timing code at all: BASELINE.md section 1). */
+int saa_device_copy_bandwidth(int32_t device, int64_t n_bytes, int32_t reps, double *bytes_per_s);
+
 /* Timing aid for bench.py: runs `nsteps` saa_step steps bracketed by HIP events recorded on the
  * handle's stream and returns the elapsed milliseconds (kernel time incl. launch gaps). */
 int saa_time_steps(saa_solver *s, int32_t nsteps, double *elapsed_ms);

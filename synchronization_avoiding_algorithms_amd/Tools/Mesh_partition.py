@@ -13,7 +13,10 @@ import numpy as np
 
 
 def part_mesh_kway(nparts, eptr, eind, group=None):
-    """Returns ``(objval, epart)``: the face cut of the partition and the part of every element of this rank's slice."""
+    """Returns ``(objval, epart)``: the part of every element of this rank's slice and, as ``objval``, the number of
+    element FACES cut by the partition (edges of the dual graph between parts).  METIS' ``objval`` is its own objective
+    (edge cut or communication volume of the graph it built from ``ncommon``): the two numbers are not comparable, and
+    the reference discards the value (``_, epart = ...``).  Fails when a part would come out empty."""
     import ctypes as C
 
     from .. import _lib

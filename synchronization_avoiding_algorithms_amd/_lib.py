@@ -20,7 +20,7 @@ HEADER = os.path.join(os.path.dirname(_HERE), "include", "saa_hip.h")
 SOURCES = ["saa_plan.cpp", "saa_partition.cpp", "saa_kernels.hip", "saa_setup.hip", "saa_api.cpp"]
 HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics", "-ldl"]
 
-ABI_VERSION = 5  # what saa_abi_version() of a matching library returns (include/saa_hip.h)
+ABI_VERSION = 6  # what saa_abi_version() of a matching library returns (include/saa_hip.h)
 SAA_OK, SAA_E_ARG, SAA_E_HIP, SAA_E_STATE, SAA_E_CAPACITY = 0, -1, -2, -3, -4
 
 
@@ -106,6 +106,7 @@ SIGNATURES = {
     "saa_halo_scatter": (C.c_int, [_H, C.c_void_p]),
     "saa_synchronize": (C.c_int, [_H]),
     "saa_time_steps": (C.c_int, [_H, C.c_int32, _dp]),
+    "saa_device_copy_bandwidth": (C.c_int, [C.c_int32, C.c_int64, C.c_int32, _dp]),
 }
 
 _lib = None

@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <utility>
@@ -126,7 +127,9 @@ struct saa_solver {
   int32_t ps_lds = 0, ps_max_items = 0, ps_steps = 0;
   int32_t ps_lds_peer = 0;  // LDS of the PEER variant: the image plus the block's push / receive records (0: does not fit)
   bool ps_capable = false;  // plan fits LDS and all workgroups can be co-resident
+  bool ps_capable_predict = false;  // ... and the PREDICT instantiation passed its own census (saa_step_predicted)
   bool ps_enabled = true;   // saa_set_resident_kernel
+  hipEvent_t ps_event = nullptr;  // recorded after every resident launch while other handles share the device
   // trajectory recorder (saa_set_recorder)
   double *rec_traj = nullptr;
   int64_t rec_cols = 0, rec_index = 0;
@@ -328,6 +331,18 @@ int check_persist_error(saa_solver *s) {
   return SAA_OK;
 }
 
+// Resident launches of ONE device must not overlap: each needs every workgroup of its grid on the chip at once, and two
+// of them (two handles or two streams in one process) would each hold a part of the CUs and wait for the rest until their
+// bounded waits give up.  The cooperative-launch API used to serialise them per device; with plain launches this does:
+// while more than one resident-capable handle lives on a device, every resident launch waits for the event recorded
+// behind the previous one (when that came from another handle) and records its own.  One handle alone pays nothing.
+constexpr int kMaxDevices = 64;
+std::mutex g_resident_mutex;
+struct ResidentDeviceState {
+  int handles = 0;              // resident-capable handles alive on this device
+  saa_solver *last = nullptr;   // whose launch was enqueued last (its ps_event marks the end of that launch)
+} g_resident[kMaxDevices];
+
 // Census: one launch of the very kernel (same variant, same registers, same LDS, same grid) in which every workgroup
 // checks in and waits for all the others - the proof of co-residency that the stamped waits of the step loop rely on.
 // 50 ms bound; a grid that does not fit keeps the one-launch-per-step kernel.
@@ -384,11 +399,38 @@ void setup_persistent(saa_solver *s) {
   s->ps_lds = lds;
   s->ps_max_items = max_items;
   s->ps_steps = 0;
-  if (!persistent_census(s, lds, 0)) {
+  // nothing else may occupy the CUs while the census counts (another handle's resident launch would make it fail)
+  if (hipDeviceSynchronize() != hipSuccess || !persistent_census(s, lds, 0)) {
+    (void)hipGetLastError();
     s->ps_entries.release();
     return;
   }
   s->ps_capable = true;
+  // the PREDICT instantiation is another kernel (other register counts): it gets its own census, and only the predicted
+  // resident path depends on it
+  s->ps_capable_predict = persistent_census(s, lds, 1);
+  if (s->device >= 0 && s->device < kMaxDevices && hipEventCreateWithFlags(&s->ps_event, hipEventDisableTiming) == hipSuccess) {
+    std::lock_guard<std::mutex> lock(g_resident_mutex);
+    ++g_resident[s->device].handles;
+  } else {
+    (void)hipGetLastError();
+    s->ps_event = nullptr;
+    s->ps_capable = s->ps_capable_predict = false;  // without the ordering event the resident path stays off
+    s->ps_entries.release();
+  }
+}
+
+// The end of a handle's part in the per-device ordering (saa_destroy).
+void retire_resident(saa_solver *s) {
+  if (!s->ps_event) return;
+  {
+    std::lock_guard<std::mutex> lock(g_resident_mutex);
+    ResidentDeviceState &d = g_resident[s->device];
+    if (d.last == s) d.last = nullptr;  // (saa_destroy has synchronised the stream: nothing of this handle is in flight)
+    --d.handles;
+  }
+  (void)hipEventDestroy(s->ps_event);
+  s->ps_event = nullptr;
 }
 
 // Exchange-free (or peer-exchange) steps through the resident kernel, in launches of at most
@@ -402,6 +444,7 @@ int try_persistent_steps(saa_solver *s, int32_t nsteps, const double *table_dev,
   if (s->det || !s->ps_capable || !s->ps_enabled || nsteps < kPersistMinSteps || !s->mesh.mass_node || !s->mesh.fext_yz)
     return SAA_OK;
   if (peer && s->ps_lds_peer == 0) return SAA_OK;
+  if (table_dev != nullptr && !s->ps_capable_predict) return SAA_OK;
   int32_t chunk = kPersistChunk;
   if (const char *env = std::getenv("SAA_PERSIST_CHUNK")) chunk = std::max(kPersistMinSteps, std::atoi(env));
   double timeout_s = 30.0;
@@ -440,11 +483,26 @@ int try_persistent_steps(saa_solver *s, int32_t nsteps, const double *table_dev,
     a.traj_cols = s->rec_cols;
     a.step_index0 = s->rec_index;
     a.save_every = s->rec_every;
-    const hipError_t e = saa::launch_persistent_steps(s->mesh, s->threads, peer ? s->ps_lds_peer : s->ps_lds, s->stream,
-                                                      s->consts, a, peer ? 2 : (table_dev != nullptr ? 1 : 0));
-    if (e != hipSuccess) {  // e.g. the device cannot hold all workgroups right now: keep the per-step path
+    hipError_t e = hipSuccess;
+    {
+      std::lock_guard<std::mutex> lock(g_resident_mutex);
+      ResidentDeviceState &d = g_resident[s->device];
+      const bool shared_device = d.handles > 1;
+      if (shared_device && d.last != nullptr && d.last != s) e = hipStreamWaitEvent(s->stream, d.last->ps_event, 0);
+      if (e == hipSuccess)
+        e = saa::launch_persistent_steps(s->mesh, s->threads, peer ? s->ps_lds_peer : s->ps_lds, s->stream, s->consts, a,
+                                         peer ? 2 : (table_dev != nullptr ? 1 : 0));
+      if (e == hipSuccess && shared_device) {
+        e = hipEventRecord(s->ps_event, s->stream);
+        d.last = s;
+      }
+    }
+    if (e != hipSuccess) {
+      // a plain launch is only refused for reasons that will not go away (invalid configuration, a lost device): the
+      // rest of this call and all later ones take one launch per step (co-residency itself is not checked here - the
+      // census at set-up established it)
       (void)hipGetLastError();
-      s->ps_capable = false;
+      s->ps_capable = s->ps_capable_predict = false;
       return SAA_OK;
     }
     s->ps_steps = static_cast<int32_t>(static_cast<uint32_t>(s->ps_steps) + static_cast<uint32_t>(n));
@@ -487,7 +545,18 @@ extern "C" {
 
 const char *saa_last_error(void) { return g_last_error.c_str(); }
 
-int32_t saa_abi_version(void) { return 5; }  // 4: saa_part_mesh_kway, saa_setup_fields; 5: saa_set_deterministic
+int32_t saa_abi_version(void) { return 6; }  // 4: saa_part_mesh_kway, saa_setup_fields; 5: saa_set_deterministic; 6: saa_device_copy_bandwidth
+
+int saa_device_copy_bandwidth(int32_t device, int64_t n_bytes, int32_t reps, double *bytes_per_s) {
+  if (!bytes_per_s || n_bytes < 16 || reps < 1) return fail(SAA_E_ARG, "saa_device_copy_bandwidth: bad argument");
+  HIP_TRY(hipSetDevice(device));
+  const hipError_t e = saa::copy_bandwidth(device, n_bytes, reps, bytes_per_s);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(SAA_E_HIP, std::string("saa_device_copy_bandwidth: ") + hipGetErrorString(e));
+  }
+  return SAA_OK;
+}
 
 int saa_plan_host_stats(int32_t n_nodes, int32_t n_elems, const double *xyz, const int32_t *tets,
                         int32_t block_nodes, saa_plan_stats *out) {
@@ -519,6 +588,8 @@ int saa_part_mesh_kway(int32_t n_parts, int32_t n_elems, int32_t n_nodes, const 
 int saa_setup_fields(int32_t device, int32_t n_nodes, int32_t n_elems, const double *xyz, const int32_t *tets, double rho,
                      double fz, double *lumped_mass_out, double *f_pre_out, double *min_edge_out) {
   if (n_nodes <= 0 || n_elems < 0 || !xyz || (n_elems > 0 && !tets)) return fail(SAA_E_ARG, "saa_setup_fields: bad argument");
+  if (4 * static_cast<int64_t>(n_elems) > INT32_MAX)  // the radix sort's pair count and the (element, corner) values are 32-bit
+    return fail(SAA_E_CAPACITY, "saa_setup_fields: more than 2^29 elements in one call");
   for (int64_t i = 0; i < 4 * static_cast<int64_t>(n_elems); ++i)
     if (tets[i] < 0 || tets[i] >= n_nodes) return fail(SAA_E_ARG, "saa_setup_fields: node id out of range");
   HIP_TRY(hipSetDevice(device));
@@ -681,7 +752,6 @@ int saa_create(const saa_problem *pb, saa_solver **out) {
   s->mesh.n_nodes = n;
   s->mesh.max_local = plan.max_local;
   s->mesh.max_owned = plan.max_owned;
-  s->mesh.force_stride = saa::force_stride_for(plan.max_owned);
   s->shared.node = s->sh_node.p;
   s->shared.slot = s->sh_slot.p;
   s->shared.foreign_slot = s->sh_foreign.p;
@@ -707,6 +777,7 @@ int saa_destroy(saa_solver *s) {
   (void)hipSetDevice(s->device);
   (void)hipStreamSynchronize(s->stream);
   if (s->comm && g_nccl.CommDestroy) (void)g_nccl.CommDestroy(s->comm);
+  retire_resident(s);
   s->release_all();
   delete s;
   return SAA_OK;
@@ -1154,7 +1225,8 @@ static int peer_attach_impl(saa_solver *s, int32_t rank, int32_t world, const ui
     int32_t max_sh = 0;
     for (size_t b = 0; b + 1 < blk_off.size(); ++b) max_sh = std::max(max_sh, blk_off[b + 1] - blk_off[b]);
     const int lds = s->ps_lds + 48 * max_sh;
-    if (lds <= 160 * 1024 && saa::configure_persistent_peer(lds) == hipSuccess && persistent_census(s, lds, 2))
+    if (lds <= 160 * 1024 && saa::configure_persistent_peer(lds) == hipSuccess && hipDeviceSynchronize() == hipSuccess &&
+        persistent_census(s, lds, 2))
       s->ps_lds_peer = lds;
   }
   s->peer_ready = true;

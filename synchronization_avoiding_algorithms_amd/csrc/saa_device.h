@@ -25,7 +25,7 @@ struct DeviceMesh {
   const int32_t *tag;  // (n_nodes)
   const int32_t *slot_sidx;  // (n_global_shared) interface slot -> index in the caller's shared list, -1 if foreign
   double lambda_, mu;
-  int32_t n_blocks, n_nodes, max_local, max_owned, force_stride;
+  int32_t n_blocks, n_nodes, max_local, max_owned;
 };
 
 // Scalars of one step, pre-computed on the host exactly as Python evaluates them

@@ -588,7 +588,7 @@ __global__ void peer_selftest_kernel(PeerMap pm, const double *__restrict__ own,
 // Resident multi-step kernel.  Same arithmetic as fused_step_kernel (item_forces, cd_update_dof), different data
 // flow: the workgroup keeps its block in LDS for the whole launch,
 //   rec   [max_local][6]  x y z ux uy uz   (x static; u of owned nodes updated in place, u of halo nodes re-read)
-//   acc   3 force planes,  dnl [3*max_owned] d^(n-1) of the owned dofs,
+//   acc   [max_owned][3] force accumulators,  dnl [3*max_owned] d^(n-1) of the owned dofs,
 //   massl / fextl [max_owned] nodal mass and (0,v,v) load,  tagl [max_owned],  connl [max_items] work items,
 //   hgl [3*max_halo] entry index of every halo dof,
 // so that per step only 48 B per owned node leave the CU (new displacements as stamped entries) and 48 B per halo
@@ -606,7 +606,8 @@ __global__ void peer_selftest_kernel(PeerMap pm, const double *__restrict__ own,
 // served by / written through to the level all XCDs share) - no L2 write-back or invalidate inside the step loop
 // (an acquire in a polling loop would invalidate the XCD's L2 on every iteration).
 
-__host__ __device__ inline int persist_off_dn(int max_local, int fstride) { return 6 * max_local + 3 * fstride; }
+// (doubles) d^(n-1) of the owned dofs follows the node records and the [max_owned][3] force accumulators
+__host__ __device__ inline int persist_off_dn(int max_local, int max_owned) { return 6 * max_local + 3 * max_owned; }
 
 #ifndef SAA_PERSIST_PRE
 #define SAA_PERSIST_PRE 2
@@ -648,11 +649,10 @@ __global__ void __launch_bounds__(SAA_LB) persistent_steps_kernel(DeviceMesh m, 
   const int pblock = plan_block(blockIdx.x, m.n_blocks);
   const BlockDesc bd = m.blocks[pblock];
   const int tid = threadIdx.x, nt = blockDim.x;
-  const int fstride = m.force_stride;
   double *rec = lds;
   double *acc = lds + 6 * m.max_local;
   // offsets (in doubles) of the arrays behind the accumulators
-  int o_dn = persist_off_dn(m.max_local, fstride), o_mass = o_dn + 3 * m.max_owned, o_fext = o_mass + m.max_owned,
+  int o_dn = persist_off_dn(m.max_local, m.max_owned), o_mass = o_dn + 3 * m.max_owned, o_fext = o_mass + m.max_owned,
       o_conn = o_fext + m.max_owned;
   int64_t base = 3 * (int64_t)bd.node_start;
   if (PEER) {
@@ -1219,8 +1219,7 @@ void launch_fused_step_ablated(int variant, const DeviceMesh &m, int threads, in
 #endif  // SAA_DIAGNOSTICS
 
 int persistent_lds_bytes(int max_local, int max_owned, int max_items, int max_halo) {
-  const int fstride = force_stride_for(max_owned);
-  const long long bytes = 8ll * (persist_off_dn(max_local, fstride) + 3 * max_owned + 2 * max_owned) + 8ll * max_items +
+  const long long bytes = 8ll * (persist_off_dn(max_local, max_owned) + 3 * max_owned + 2 * max_owned) + 8ll * max_items +
                           4ll * max_owned + 12ll * max_halo + 16;
   return bytes <= 160 * 1024 ? (int)((bytes + 15) / 16 * 16) : 0;
 }

@@ -315,13 +315,17 @@ bool partition_kway(int32_t n_parts, int32_t n_elems, int32_t n_nodes, const int
   epart.assign(n_elems, 0);
   st = PartitionStats();
   if (n_elems == 0) return true;
+  if (n_parts > n_elems) {  // a rank without elements fails much later (plan build) with an unrelated message
+    err = "partition_kway: " + std::to_string(n_parts) + " parts asked of " + std::to_string(n_elems) + " elements";
+    return false;
+  }
   Dual g;
   build_dual(n_elems, tets, g);
   if (n_parts > 1) {
     Bisector bis(g, epart);
     std::vector<int32_t> all(n_elems);
     std::iota(all.begin(), all.end(), 0);
-    recurse(bis, epart, all, std::min(n_parts, n_elems), 0);
+    recurse(bis, epart, all, n_parts, 0);
   }
   // statistics
   std::vector<int64_t> size(n_parts, 0);
@@ -334,6 +338,11 @@ bool partition_kway(int32_t n_parts, int32_t n_elems, int32_t n_nodes, const int
   }
   st.min_part = *std::min_element(size.begin(), size.end());
   st.max_part = *std::max_element(size.begin(), size.end());
+  if (st.min_part == 0) {  // (a bisection of a very small or disconnected piece left one side empty)
+    err = "partition_kway: a part came out empty (" + std::to_string(n_elems) + " elements in " + std::to_string(n_parts) +
+          " parts)";
+    return false;
+  }
   std::vector<int32_t> first(n_nodes, -1);
   std::vector<uint8_t> shared(n_nodes, 0);
   for (int32_t e = 0; e < n_elems; ++e)

@@ -25,15 +25,15 @@ struct BlockDesc {
 };
 
 // LDS image of a block (doubles): node records [n_local][6] = x y z ux uy uz (48 B, 16-B aligned: three
-// ds_read_b128 per node), then three force planes fx[], fy[], fz[] of `force_stride` doubles (multiple of 32,
-// so that the plane of a node sits in bank pair (node mod 32) for every component).
+// ds_read_b128 per node), then the force accumulators [n_owned][3] (AoS: one address computation per node, the
+// components at immediate offsets).
 //   * ds_read_b128 is executed per 16-lane group; lanes of a group collide unless their nodes differ mod 16
 //     (record start bank = 12*node mod 64 takes 16 distinct values);
-//   * ds_add_f64 is executed per 32-lane half; lanes collide unless their nodes differ mod 32.
+//   * ds_add_f64 is executed per 32-lane half; lanes collide unless their nodes differ mod 32 (accumulator start bank
+//     = 6*node mod 64).
 // The plan packs elements so that both hold as far as possible (reorder_for_lds).
-inline int32_t force_stride_for(int32_t max_owned) { return (max_owned + 31) / 32 * 32; }
 inline int32_t lds_bytes_for(int32_t max_local, int32_t max_owned) {
-  return 8 * (6 * max_local + 3 * force_stride_for(max_owned));
+  return (8 * (6 * max_local + 3 * max_owned) + 15) / 16 * 16;
 }
 
 struct Plan {

@@ -143,15 +143,10 @@ hipError_t setup_fields(int32_t n_nodes, int32_t n_elems, const double *xyz_host
     int end_bit = 1;
     while (end_bit < 31 && (1ll << end_bit) < n_nodes) ++end_bit;
     SETUP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys, keys_s, vals, vals_s, static_cast<int>(n_pairs), 0, end_bit));
-    void *tmp = nullptr;
-    SETUP_TRY(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
-    const hipError_t se = hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, keys, keys_s, vals, vals_s, static_cast<int>(n_pairs), 0, end_bit);
-    if (se != hipSuccess) {
-      (void)hipFree(tmp);
-      return se;
-    }
+    char *tmp = nullptr;  // (owned by `sc`: freed on every exit path)
+    SETUP_TRY(sc.alloc(&tmp, tmp_bytes ? tmp_bytes : 16));
+    SETUP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, keys, keys_s, vals, vals_s, static_cast<int>(n_pairs), 0, end_bit));
     SETUP_TRY(hipDeviceSynchronize());
-    (void)hipFree(tmp);
   }
   hipLaunchKernelGGL(segment_offsets_kernel, dim3((unsigned)((n_pairs + 1 + threads - 1) / threads)), dim3(threads), 0, nullptr,
                      n_pairs, n_nodes, keys_s, offsets);
@@ -172,6 +167,51 @@ hipError_t setup_fields(int32_t n_nodes, int32_t n_elems, const double *xyz_host
     *min_edge_host = n_elems > 0 ? __builtin_sqrt(len2) : 0.0;
   }
   return hipSuccess;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Device-to-device copy rate of this GPU: the practical HBM ceiling next to the nominal 8 TB/s.
+// 16 bytes per lane (global_load_dwordx4 / global_store_dwordx4), grid-stride, 8 workgroups of 256 threads per CU, four
+// independent loads in flight per lane - the "float4 copy" MI355X_MICROARCH.md quotes 6.29 TB/s for.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) copy16_kernel(const double2 *__restrict__ src, double2 *__restrict__ dst, int64_t n) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  for (; i + 3 * stride < n; i += 4 * stride) {
+    const double2 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+    dst[i] = a;
+    dst[i + stride] = b;
+    dst[i + 2 * stride] = c;
+    dst[i + 3 * stride] = d;
+  }
+  for (; i < n; i += stride) dst[i] = src[i];
+}
+
+hipError_t copy_bandwidth(int device, int64_t n_bytes, int reps, double *bytes_per_s) {
+  Scratch sc;
+  const int64_t n = n_bytes / 16;
+  double2 *a, *b;
+  int cus = 0;
+  SETUP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
+  SETUP_TRY(sc.alloc(&a, static_cast<size_t>(n)));
+  SETUP_TRY(sc.alloc(&b, static_cast<size_t>(n)));
+  SETUP_TRY(hipMemset(a, 0x3c, static_cast<size_t>(n) * 16));  // finite, non-zero doubles
+  hipEvent_t e0, e1;
+  SETUP_TRY(hipEventCreate(&e0));
+  SETUP_TRY(hipEventCreate(&e1));
+  const dim3 grid(static_cast<unsigned>(8 * (cus > 0 ? cus : 256)));
+  for (int r = 0; r < 2; ++r) hipLaunchKernelGGL(copy16_kernel, grid, dim3(256), 0, nullptr, a, b, n);  // warm
+  hipError_t e = hipEventRecord(e0, nullptr);
+  for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(copy16_kernel, grid, dim3(256), 0, nullptr, a, b, n);
+  if (e == hipSuccess) e = hipEventRecord(e1, nullptr);
+  if (e == hipSuccess) e = hipEventSynchronize(e1);
+  float ms = 0.f;
+  if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+  if (e == hipSuccess) e = hipGetLastError();
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  if (e == hipSuccess) *bytes_per_s = ms > 0.f ? 2.0 * 16.0 * static_cast<double>(n) * reps / (ms * 1e-3) : 0.0;
+  return e;
 }
 
 }  // namespace saa

@@ -7,25 +7,31 @@ import sys
 import pytest
 
 pytestmark = pytest.mark.gpu
+SA_EPOCHS = 60
+SA_ERR_BOUNDS = (0.5, 0.5, 0.5)  # per predicted window, see test_two_ranks_launch_themselves_and_print_one_line
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(*flags, timeout=900):
+def _run(*flags, timeout=900, extra_env=None, expect_rc=0):
     env = dict(os.environ)
-    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "SAA_BENCH_T0"):
         env.pop(k, None)
+    env.update(extra_env or {})
     r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), *flags], capture_output=True, text=True,
                        timeout=timeout, env=env, cwd=REPO)
-    assert r.returncode == 0, r.stderr[-3000:]
+    if expect_rc == 0:
+        assert r.returncode == 0, r.stderr[-3000:]
+    else:
+        assert r.returncode != 0, r.stdout[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, r.stdout[-2000:]
+    assert len(lines) == 1, (r.stdout[-2000:], r.stderr[-2000:])
     return json.loads(lines[0])
 
 
 def test_two_ranks_launch_themselves_and_print_one_line():
     """N = 2 on the one-GPU box: both ranks share cuda:0, gloo process group (what --same-device is for)."""
     out = _run("--gpus", "2", "--same-device", "--backend", "gloo", "--refine", "4", "--steps", "40", "--warmup", "10",
-               "--sa-train-seconds", "8", "--sa-truth-steps", "24000")
+               "--sa-train-epochs", str(SA_EPOCHS), "--sa-truth-steps", "24000")
     assert out["n_gpus"] == 2 and out["steps"] == 40 and out["warmup"] == 10 and out["timed_calls"] >= 1
     assert out["metric"] == "element_updates_per_s" and out["value"] > 0 and out["scaling"] == "weak"
     assert "2 x-slab" in out["config"]["workload"]
@@ -33,10 +39,38 @@ def test_two_ranks_launch_themselves_and_print_one_line():
     # configs[4]: models trained in the run on the synchronised history, accuracy reported per window
     sa = out["sync_avoiding"]
     assert sa["value"] > 0 and sa["state_finite"] and sa["steps"] == 3 * 3000
-    # (a model trained for 8 seconds: the bound only says that the windows follow the synchronised run)
-    assert len(sa["rel_l2_vs_synchronised"]) == 3 and all(0 <= e < 0.5 for e in sa["rel_l2_vs_synchronised"]), sa
+    # A FIXED number of epochs with fixed seeds (the time bound is only a cap): what the model is does not depend on how
+    # busy the box is.  The bounds are 3x what this very configuration gave on MI355X (profiles/r03_sa_fixed_epochs.txt);
+    # what is left to vary is fp32 summation order inside MIOpen.
     tr = sa["training"]
-    assert tr["epochs"] >= 1 and tr["train_mse_first_last"][1] < tr["train_mse_first_last"][0]
+    assert tr["epochs"] == tr["epochs_min_over_ranks"] == SA_EPOCHS and tr["schedule"] == "fixed epoch count", tr
+    assert tr["train_mse_first_last"][1] < 0.05 * tr["train_mse_first_last"][0], tr
+    errs = sa["rel_l2_vs_synchronised"]
+    assert len(errs) == 3 and all(0 <= e < b for e, b in zip(errs, SA_ERR_BOUNDS)), (errs, SA_ERR_BOUNDS)
+    assert out["legs"]["headline"] == "done" and out["legs"]["sync_avoiding"] == "done", out["legs"]
+    assert out["leg_seconds"]["total"] < out["budget_s"]
+
+
+def test_line_survives_a_hung_preflight_and_a_stalled_rccl_leg():
+    """The 8-GPU record must never be lost to a leg that misbehaves: with the preflight child hanging
+    and the RCCL leg stalled for good, the run still prints its one line - headline and sync-avoiding leg measured, the
+    failed legs marked - inside its budget, and leaves with a non-zero status so that the hang is seen."""
+    import time
+
+    t0 = time.time()
+    out = _run("--gpus", "2", "--same-device", "--backend", "gloo", "--refine", "4", "--steps", "40", "--warmup", "10",
+               "--sa-train-epochs", "3", "--sa-truth-steps", "12000", "--budget-s", "240", expect_rc=3,
+               extra_env={"SAA_BENCH_FORCE_PREFLIGHT": "1", "SAA_BENCH_TEST_PREFLIGHT": "hang",
+                          "SAA_BENCH_FORCE_RCCL_LEG": "1", "SAA_BENCH_TEST_STALL_RCCL": "1"})
+    wall = time.time() - t0
+    assert wall < 240 + 20, wall
+    assert out["value"] > 0 and out["config"]["peer_preflight_rank0"] is False
+    assert "all-reduce" in out["config"]["exchange"]  # the fall-back transport carried the headline
+    legs = out["legs"]
+    assert legs["preflight"].startswith("failed or exceeded") and out["leg_seconds"]["preflight"] <= 62
+    assert legs["headline"] == "done" and legs["sync_avoiding"] == "done" and out["sync_avoiding"]["value"] > 0
+    assert legs["rccl_allreduce"].startswith("unfinished") and out["rccl_allreduce"]["value"] is None
+    assert out["leg_seconds"]["total"] <= 240
 
 
 def test_headline_at_the_drivers_flags_is_warm():
@@ -45,6 +79,9 @@ def test_headline_at_the_drivers_flags_is_warm():
     out = _run("--gpus", "1", "--steps", "20", "--warmup", "5", "--no-cpu-baseline")
     roof = out["roofline"]
     assert roof["launches_timed"] >= 10 and 0.3 < roof["frac"] < 1.5
+    # the practical HBM ceiling comes from the library's own 16-byte-per-lane copy kernel (the guide: 6.29 TB/s)
+    assert 4500 < roof["measured_copy_GBps"] < 8000, roof["measured_copy_GBps"]
+    assert out["legs"]["roofline"] == "done" and out["legs"]["cpu_baseline"].startswith("skipped")
     kernel_rate = 1028850 / (roof["us_per_step"] * 1e-6)
     assert out["value"] > kernel_rate / 1.5, (out["value"], kernel_rate)
     assert out["timed_calls"] * out["steps"] * out["ms_per_step"] >= 45.0  # the timed region lasted >= ~50 ms

@@ -428,6 +428,41 @@ def test_resident_grid_sizing_several_blocks_per_cu_and_oversized_grids(monkeypa
     forced.close()
 
 
+def test_two_handles_step_resident_on_two_streams_at_once():
+    """Two solvers in one process, each with its own stream, each with a resident grid that fills the chip (256 workgroups
+    of the 1M-tet beam): their resident launches must not overlap - each would hold a part of the CUs and wait for the
+    rest until the bounded waits give up (SAA_E_STATE, trajectory lost).  The library orders the resident launches of a
+    device among themselves; both trajectories come out right, and equal to one launch per step."""
+    import torch
+
+    from synchronization_avoiding_algorithms_amd.mesh import structured_beam
+
+    mesh = structured_beam(19)
+    a, _, _, _, _ = _serial_solver(mesh)
+    b, _, _, _, _ = _serial_solver(mesh)
+    assert a.resident_kernel_info()["capable"] and b.resident_kernel_info()["capable"]
+    assert a.plan_stats()["n_blocks"] > 128  # two such grids cannot be on the chip together
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    a.set_stream(sa.cuda_stream)
+    b.set_stream(sb.cuda_stream)
+    for _ in range(3):  # enqueued back to back on two streams, nothing waits on the host
+        a.step(200)
+        b.step(200)
+    a.synchronize()     # raises if a bounded wait inside a resident kernel gave up
+    b.synchronize()
+    a0, an, ta = a.get_state()
+    b0, bn, tb = b.get_state()
+    assert ta == tb and np.abs(a0).max() > 0
+    assert rel_l2(a0, b0) < 1e-12 and rel_l2(an, bn) < 1e-12
+    b.set_resident_kernel(False)
+    b.set_state(np.zeros(b.n_dof), np.zeros(b.n_dof), 0.0)
+    b.step(600)
+    c0, cn, _ = b.get_state()
+    assert rel_l2(a0, c0) < 1e-12 and rel_l2(an, cn) < 1e-12
+    a.close()
+    b.close()
+
+
 def test_deterministic_mode_is_bit_reproducible_and_equals_the_atomic_path(monkeypatch):
     """``saa_set_deterministic``: the atomic-free two-kernel step sums a node's element forces in a fixed order.  Two
     independent solvers give IDENTICAL bits after 400 steps and for K.d (the LDS-atomic kernels only agree to round-off

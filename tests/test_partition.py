@@ -76,9 +76,21 @@ def test_edge_cases(beam_coarse):
     two, st = graph_partition(beam_coarse, 2, return_stats=True)
     assert abs(int((two == 0).sum()) - 128) <= 2 and st["face_cut"] > 0
     tiny = Mesh(np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1.0], [1, 1, 1]]), {"tetra": np.array([[0, 1, 2, 3], [1, 2, 3, 4]])})
-    assert sorted(graph_partition(tiny, 5).tolist()) == [0, 1]  # more parts than elements: one element per part
+    assert sorted(graph_partition(tiny, 2).tolist()) == [0, 1]
+    with pytest.raises(_lib.SaaError, match="parts asked of"):  # more parts than elements: some rank would get nothing
+        graph_partition(tiny, 5)
     with pytest.raises(_lib.SaaError):
         graph_partition(Mesh(tiny.points, {"tetra": np.array([[0, 1, 2, 9]])}), 2)
+
+
+@pytest.mark.parametrize("k", [2, 3, 5, 8])
+def test_no_part_is_empty_on_a_tiny_mesh(k):
+    """A rank without elements would only fail later, in the plan build, with an unrelated message: every part of a
+    k-way partition holds at least one element (or the call fails)."""
+    mesh = structured_beam(1)  # 150 tets
+    epart, st = graph_partition(mesh, k, return_stats=True)
+    assert sorted(set(epart.tolist())) == list(range(k)) and st["min_part"] >= 1
+    assert st["max_part"] - st["min_part"] <= max(2, 0.1 * 150 / k)
 
 
 def test_dropin_part_mesh_kway_signature(beam_coarse):

@@ -16,10 +16,11 @@ from synchronization_avoiding_algorithms_amd.mesh import structured_beam  # noqa
 
 # usage: persist_stamps.py [n [parts rank [peer]]]   (parts > 1: the x-slab partition `rank` of `parts`; exchange-free steps,
 #                                                      or - "peer" - steps through the peer exchange with loop-back)
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 19
-parts = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-prank = int(sys.argv[3]) if len(sys.argv) > 3 else 0
-peer = len(sys.argv) > 4 and sys.argv[4] == "peer"
+pos = [a for a in sys.argv[1:] if not a.startswith("--")]
+n = int(pos[0]) if len(pos) > 0 else 19
+parts = int(pos[1]) if len(pos) > 1 else 1
+prank = int(pos[2]) if len(pos) > 2 else 0
+peer = len(pos) > 3 and pos[3] == "peer"
 steps = 1000
 mesh = structured_beam(n)
 sol, lay, _, _ = build_rank_solver(mesh, parts, prank, 0)
@@ -59,3 +60,11 @@ print("  slowest update workgroups:", [(int(b), int(wg[b, 6]), int(wg[b, 0] + wg
 if not peer:
     ms = sol.time_steps(1000)
     print(f"stamped build: {ms:.3f} us/step")
+for a in sys.argv[1:]:
+    if a.startswith("--json="):  # medians for tools/onchip_summary.py
+        import json
+
+        med = [float(np.median(t[:, j])) for j in range(8)]
+        with open(a.split("=", 1)[1], "w") as fh:
+            json.dump({"n": n, "cycles_per_step_median_total": float(np.median(tot)), "phases": dict(zip(names, med)),
+                       "barrier_cycles": med[3] + med[5] + med[7]}, fh, indent=1)
