@@ -400,7 +400,9 @@ def sync_avoiding_leg(part, args, rank, world, ne_total, fence, train_seconds):
             with torch.enable_grad():
                 model, smax, smin, tl, vl = tr.train_on_history(truth, n_s, n_p, n_f, cut_off=1.0, seed=1234 + rank,
                                                                 hidden_size=hid, num_epochs=epochs,
-                                                                max_seconds=train_seconds / turns)
+                                                                max_seconds=train_seconds / turns,
+                                                                verbose=True, rank=0 if turns > 1 else rank,
+                                                                log=sys.stderr)  # (progress: stdout is the line's)
         if turns > 1:
             fence()
     fence()
@@ -782,7 +784,7 @@ def main():
                                          "(not HBM: see hbm_measured)")
         copy_bw = measured_copy_bandwidth(local_rank)
         roof["measured_copy_GBps"] = copy_bw / 1e9
-        roof["measured_copy_kernel"] = "saa_device_copy_bandwidth: 16 B per lane, 1 GiB -> 1 GiB, 10 launches"
+        roof["measured_copy_kernel"] = "saa_device_copy_bandwidth: one 16-byte element per thread, 1 GiB -> 1 GiB, 10 launches"
         roof["frac_of_measured_copy"] = achieved / copy_bw
         put("roofline", roof)
         legs.end("roofline")

@@ -76,7 +76,11 @@ typedef struct saa_plan_stats {
   int64_t n_halo_total;     /* sum over blocks of halo nodes */
   int32_t lds_bytes;        /* dynamic LDS per workgroup */
   int32_t threads;          /* workgroup size in use */
-  double lds_conflict_factor; /* mean worst LDS bank multiplicity per (half-wave, vertex slot); 1 = none */
+  double lds_conflict_factor; /* mean worst LDS bank multiplicity of the record reads per (lane group, vertex slot); 1 = none */
+  double lds_atomic_conflict_factor; /* the same for the force accumulation (ds_add_f64) per (half-wave, vertex slot) */
+  int64_t n_items;          /* work items (pairs of face-adjacent elements, single elements, idle slots of the packing) */
+  int64_t n_pairs;          /* items that hold two elements */
+  int64_t n_by_construction; /* item slots in half-waves that are clash-free by construction (pattern classes) */
 } saa_plan_stats;
 
 const char *saa_last_error(void);

@@ -121,6 +121,13 @@ struct saa_solver {
   std::vector<double> host_tmp;
   void *comm = nullptr;  // ncclComm_t of the native exchange (saa_comm_init)
   int32_t comm_world = 0;
+  // saa_step_synced as replayed HIP graphs: three steps (the rotation period of the state buffers) per graph, one graph
+  // per rotation phase; the clock lives in device memory (tn3: the time of d^n of step j in slot j % 3)
+  DevBuf<double> tn3;
+  hipGraphExec_t sync_graph[3] = {nullptr, nullptr, nullptr};
+  hipStream_t sync_graph_stream = nullptr;
+  double *sync_graph_iface = nullptr;
+  bool sync_graph_off = false;
   // resident multi-step kernel (saa_device.h: PersistArgs)
   DevBuf<int32_t> ps_err;
   DevBuf<saa::PeerEntry> ps_entries;  // 2 x 3*n_nodes stamped displacements
@@ -180,6 +187,11 @@ struct saa_solver {
     for (auto &b : scratch) b.release();
     ps_entries.release(); ps_err.release();
     det_force.release(); det_off.release(); det_contrib.release();
+    for (auto &g : sync_graph) {
+      if (g) (void)hipGraphExecDestroy(g);
+      g = nullptr;
+    }
+    tn3.release();
     for (void *q : peer_open) (void)hipIpcCloseMemHandle(q);
     peer_open.clear();
     if (peer_mem) (void)hipFree(peer_mem);
@@ -215,6 +227,10 @@ void fill_stats(const saa::Plan &plan, int lds, int threads, saa_plan_stats *out
   out->lds_bytes = lds;
   out->threads = threads;
   out->lds_conflict_factor = plan.lds_conflict_factor;
+  out->lds_atomic_conflict_factor = plan.lds_atomic_conflict_factor;
+  out->n_items = plan.n_items;
+  out->n_pairs = plan.n_pairs;
+  out->n_by_construction = plan.n_by_construction;
 }
 
 bool build_fitting_plan(int32_t n_nodes, int32_t n_elems, const double *xyz, const int32_t *tets,
@@ -533,6 +549,80 @@ void launch_force(saa_solver *s, const double *d, double *f) {
     saa::launch_force_only(s->mesh, s->threads, s->lds_bytes, s->stream, d, f);
 }
 
+// Synchronised steps (fused kernel -> ncclAllReduce -> finish kernel) as replayed HIP graphs: three launches per step
+// and a collective's enqueue cost make the RCCL transport launch-bound from the host.  One graph holds THREE steps - after
+// three the rotating state buffers are back where they were, so the captured pointers stay right - and there is one graph
+// per rotation phase it can start from.  What changes from step to step inside a graph may not be a launch argument:
+// the time of d^n (hence the ramp) lives in device memory, advanced by the finish kernel exactly as the host advances its
+// copy.  Steps that record history rows or trajectory columns (their addresses change every step), deterministic mode and
+// calls shorter than six steps keep the eager path.  *n_done: steps taken here (a multiple of three).
+int try_synced_graphs(saa_solver *s, int32_t nsteps, bool wants_hist, int32_t *n_done) {
+  *n_done = 0;
+  if (s->sync_graph_off || wants_hist || s->rec_traj || s->det || nsteps < 6) return SAA_OK;
+  if (const char *env = std::getenv("SAA_SYNCED_GRAPH"))
+    if (env[0] == '0') return SAA_OK;
+  const size_t count = 3 * static_cast<size_t>(s->n_global_shared);
+  if (s->sync_graph_stream != s->stream || s->sync_graph_iface != s->iface) {  // captured for another stream / buffer
+    for (auto &g : s->sync_graph) {
+      if (g) (void)hipGraphExecDestroy(g);
+      g = nullptr;
+    }
+    s->sync_graph_stream = s->stream;
+    s->sync_graph_iface = s->iface;
+  }
+  if (!s->tn3.p && s->tn3.alloc(3) != hipSuccess) {
+    (void)hipGetLastError();
+    s->sync_graph_off = true;
+    return SAA_OK;
+  }
+  const int phase = s->i0;  // which buffer holds d^n identifies the rotation phase
+  if (!s->sync_graph[phase]) {
+    hipGraph_t graph = nullptr;
+    // relaxed mode: other threads of the process (PyTorch's collective watchdog polls events) must not break the capture
+    hipError_t e = hipStreamBeginCapture(s->stream, hipStreamCaptureModeRelaxed);
+    int nccl_rc = 0;
+    if (e == hipSuccess) {
+      int i0 = s->i0, in_ = s->in_, i1 = s->i1;
+      for (int j = 0; j < 3; ++j) {
+        const double *tn_j = s->ramp ? s->tn3.p + j : nullptr;
+        saa::StepConsts k = s->consts;
+        k.ramp = 1.0;  // (ramp off; with the ramp on the kernels overwrite it from the device clock)
+        saa::launch_fused_step(s->mesh, s->threads, s->lds_bytes, s->stream, s->dbuf[i0].p, s->dbuf[in_].p, s->dbuf[i1].p,
+                               s->iface, nullptr, nullptr, k, tn_j);
+        if (count > 0 && nccl_rc == 0)
+          nccl_rc = g_nccl.AllReduce(s->iface, s->iface, count, kNcclDouble, kNcclSum, s->comm, s->stream);
+        saa::launch_iface_finish(s->mesh, s->shared, s->stream, s->dbuf[i0].p, s->dbuf[in_].p, s->dbuf[i1].p, s->iface,
+                                 nullptr, k, s->tn3.p + j, s->tn3.p + (j + 1) % 3);
+        const int old_n = in_;
+        in_ = i0;
+        i0 = i1;
+        i1 = old_n;
+      }
+      e = hipStreamEndCapture(s->stream, &graph);
+    }
+    hipGraphExec_t exec = nullptr;
+    if (e == hipSuccess && nccl_rc == 0 && graph) e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    if (graph) (void)hipGraphDestroy(graph);
+    if (e != hipSuccess || nccl_rc != 0 || !exec) {  // this RCCL / runtime cannot capture it: eager from now on
+      (void)hipGetLastError();
+      if (exec) (void)hipGraphExecDestroy(exec);
+      s->sync_graph_off = true;
+      return SAA_OK;
+    }
+    s->sync_graph[phase] = exec;
+  }
+  const int32_t replays = nsteps / 3;
+  saa::launch_set_scalar(s->stream, s->tn3.p, s->tn);  // the device clock starts at this call's time
+  for (int32_t r = 0; r < replays; ++r) {
+    const hipError_t e = hipGraphLaunch(s->sync_graph[phase], s->stream);
+    if (e != hipSuccess) return fail(SAA_E_HIP, std::string("saa_step_synced: hipGraphLaunch: ") + hipGetErrorString(e));
+    for (int j = 0; j < 3; ++j) s->tn = s->tn + s->consts.dt;  // the finish kernels advanced their copy the same way
+  }
+  s->rec_index += 3 * static_cast<int64_t>(replays);
+  *n_done = 3 * replays;  // (three rotations: i0 / in_ / i1 are where they were)
+  return SAA_OK;
+}
+
 int check_launch() {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(SAA_E_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
@@ -545,7 +635,7 @@ extern "C" {
 
 const char *saa_last_error(void) { return g_last_error.c_str(); }
 
-int32_t saa_abi_version(void) { return 6; }  // 4: saa_part_mesh_kway, saa_setup_fields; 5: saa_set_deterministic; 6: saa_device_copy_bandwidth
+int32_t saa_abi_version(void) { return 7; }  // 4: saa_part_mesh_kway, saa_setup_fields; 5: saa_set_deterministic; 6: saa_device_copy_bandwidth; 7: saa_plan_stats grew
 
 int saa_device_copy_bandwidth(int32_t device, int64_t n_bytes, int32_t reps, double *bytes_per_s) {
   if (!bytes_per_s || n_bytes < 16 || reps < 1) return fail(SAA_E_ARG, "saa_device_copy_bandwidth: bad argument");
@@ -962,7 +1052,9 @@ int saa_step_synced(saa_solver *s, int32_t nsteps, double *hist_dev, int64_t his
   HIP_TRY(hipSetDevice(s->device));
   const size_t count = 3 * static_cast<size_t>(s->n_global_shared);
   const int64_t width = 3 * static_cast<int64_t>(s->n_shared);
-  for (int32_t k = 0; k < nsteps; ++k) {
+  int32_t k0 = 0;
+  if (int rc = try_synced_graphs(s, nsteps, hist_dev != nullptr, &k0)) return rc;
+  for (int32_t k = k0; k < nsteps; ++k) {
     s->set_ramp();
     launch_step(s, s->iface, nullptr, nullptr);
     if (count > 0) {

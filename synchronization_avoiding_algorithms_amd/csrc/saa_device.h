@@ -155,17 +155,21 @@ hipError_t configure_det_kernels(int lds_bytes);
 void launch_det_step(const DeviceMesh &m, const DetLists &det, int threads, int lds_bytes, hipStream_t st, const double *d0,
                      const double *dn, double *out, double *iface, const double *table_row, double *hist_row,
                      const StepConsts &k, bool force_only);
+// tn_dev (nullable): take the ramp from the time stored there instead of k.ramp (graph-replayed steps)
 void launch_fused_step(const DeviceMesh &m, int threads, int lds_bytes, hipStream_t st, const double *d0,
                        const double *dn, double *d1, double *iface, const double *table_row, double *hist_row,
-                       const StepConsts &k);
+                       const StepConsts &k, const double *tn_dev = nullptr);
+void launch_set_scalar(hipStream_t st, double *p, double v);
 #ifdef SAA_DIAGNOSTICS
 void launch_fused_step_ablated(int variant, const DeviceMesh &m, int threads, int lds_bytes, hipStream_t st,
                                const double *d0, const double *dn, double *d1, const StepConsts &k, double *dbg);
 #endif
 void launch_force_only(const DeviceMesh &m, int threads, int lds_bytes, hipStream_t st, const double *d,
                        double *f);
+// tn_in / tn_out (nullable pair): device-side clock of graph-replayed steps - ramp from *tn_in, *tn_out = *tn_in + dt
 void launch_iface_finish(const DeviceMesh &m, const SharedMap &sh, hipStream_t st, const double *d0,
-                         const double *dn, double *d1, double *iface, double *hist_row, const StepConsts &k);
+                         const double *dn, double *d1, double *iface, double *hist_row, const StepConsts &k,
+                         const double *tn_in = nullptr, double *tn_out = nullptr);
 void launch_halo_overwrite(const SharedMap &sh, hipStream_t st, const double *row, double *d1, double *hist_row);
 void launch_halo_gather(const SharedMap &sh, hipStream_t st, const double *d, double *row);
 void launch_cd_update(const DeviceMesh &m, hipStream_t st, const double *f_int, const double *d0,

@@ -342,8 +342,14 @@ template <bool FORCE_ONLY, int ABLATE = 0, bool PEER = false>
 __global__ void __launch_bounds__(SAA_LB) fused_step_kernel(DeviceMesh m, const double *__restrict__ d0, const double *__restrict__ dn,
                                   double *__restrict__ out, double *__restrict__ iface,
                                   const double *__restrict__ table_row, double *__restrict__ hist_row, StepConsts k,
-                                  const PeerMap *__restrict__ pmap, unsigned seq) {
+                                  const PeerMap *__restrict__ pmap, unsigned seq, const double *__restrict__ tn_dev) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
+  // graph-replayed steps (saa_step_synced): the time of d^n lives in device memory, the ramp follows from it here
+  // (linear_ramp, commons.py:7-11) instead of arriving as a launch argument
+  if (tn_dev != nullptr) {
+    const double t = *tn_dev;
+    k.ramp = t <= 1 ? t : 1.0;
+  }
   // (ABLATE == 9: eight steps' worth of blocks in one launch - what the launch boundary and its tail cost)
   const int pblock = plan_block(ABLATE == 9 ? blockIdx.x % m.n_blocks : blockIdx.x, m.n_blocks);
   const BlockDesc bd = m.blocks[pblock];
@@ -564,13 +570,15 @@ __global__ void __launch_bounds__(SAA_LB) fused_step_kernel(DeviceMesh m, const 
   }
 }
 
-template __global__ void fused_step_kernel<false>(DeviceMesh, const double *, const double *, double *,
-                                                   double *, const double *, double *, StepConsts, const PeerMap *, unsigned);
-template __global__ void fused_step_kernel<true>(DeviceMesh, const double *, const double *, double *,
-                                                  double *, const double *, double *, StepConsts, const PeerMap *, unsigned);
-template __global__ void fused_step_kernel<false, 0, true>(DeviceMesh, const double *, const double *, double *,
-                                                            double *, const double *, double *, StepConsts,
-                                                            const PeerMap *, unsigned);
+template __global__ void fused_step_kernel<false>(DeviceMesh, const double *, const double *, double *, double *,
+                                                   const double *, double *, StepConsts, const PeerMap *, unsigned,
+                                                   const double *);
+template __global__ void fused_step_kernel<true>(DeviceMesh, const double *, const double *, double *, double *,
+                                                  const double *, double *, StepConsts, const PeerMap *, unsigned,
+                                                  const double *);
+template __global__ void fused_step_kernel<false, 0, true>(DeviceMesh, const double *, const double *, double *, double *,
+                                                            const double *, double *, StepConsts, const PeerMap *, unsigned,
+                                                            const double *);
 
 // Attach-time proof of the peer path: one exchange of known values (own[3*q+c], node-sorted order) -> the sums
 // in the caller's shared order.
@@ -1069,10 +1077,18 @@ __global__ void det_nodes_kernel(DeviceMesh m, DetLists det, const double *__res
 // After the all-reduce: shared nodes get the update from the summed force (Dynamic_solver.py:26-32),
 // optional history record (Online_predictor.py:260); slots of shared nodes this rank does not hold
 // are zeroed so that the next all-reduce sees only fresh partial forces.
+// tn_in / tn_out (graph-replayed steps): the device-side clock - every thread takes the ramp from *tn_in, one thread
+// writes *tn_out = *tn_in + dt (Data_prepare.py:235; another slot: no thread of this launch reads what it writes).
 __global__ void iface_finish_kernel(DeviceMesh m, SharedMap sh, const double *__restrict__ d0,
                                     const double *__restrict__ dn, double *__restrict__ d1,
-                                    double *__restrict__ iface, double *__restrict__ hist_row, StepConsts k) {
+                                    double *__restrict__ iface, double *__restrict__ hist_row, StepConsts k,
+                                    const double *__restrict__ tn_in, double *__restrict__ tn_out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tn_in != nullptr) {
+    const double t = *tn_in;
+    k.ramp = t <= 1 ? t : 1.0;
+    if (i == 0) *tn_out = t + k.dt;
+  }
   const int n_local = 3 * sh.n_shared;
   if (i < n_local) {
     const int s = i / 3, c = i - 3 * s;
@@ -1163,9 +1179,14 @@ hipError_t configure_kernels(int lds_bytes) {
 
 void launch_fused_step(const DeviceMesh &m, int threads, int lds_bytes, hipStream_t st, const double *d0,
                        const double *dn, double *d1, double *iface, const double *table_row, double *hist_row,
-                       const StepConsts &k) {
+                       const StepConsts &k, const double *tn_dev) {
   hipLaunchKernelGGL(fused_step_kernel<false>, dim3(m.n_blocks), dim3(threads), lds_bytes, st, m, d0, dn, d1,
-                     iface, table_row, hist_row, k, static_cast<const PeerMap *>(nullptr), 0u);
+                     iface, table_row, hist_row, k, static_cast<const PeerMap *>(nullptr), 0u, tn_dev);
+}
+
+__global__ void set_scalar_kernel(double *p, double v) { *p = v; }
+void launch_set_scalar(hipStream_t st, double *p, double v) {
+  hipLaunchKernelGGL(set_scalar_kernel, dim3(1), dim3(1), 0, st, p, v);
 }
 
 hipError_t configure_det_kernels(int lds_bytes) {
@@ -1188,7 +1209,8 @@ void launch_fused_step_peer(const DeviceMesh &m, int threads, int lds_bytes, hip
                             const double *dn, double *d1, double *hist_row, const StepConsts &k,
                             const PeerMap *pm_dev, unsigned seq) {
   hipLaunchKernelGGL((fused_step_kernel<false, 0, true>), dim3(m.n_blocks), dim3(threads), lds_bytes, st, m, d0, dn,
-                     d1, static_cast<double *>(nullptr), static_cast<const double *>(nullptr), hist_row, k, pm_dev, seq);
+                     d1, static_cast<double *>(nullptr), static_cast<const double *>(nullptr), hist_row, k, pm_dev, seq,
+                     static_cast<const double *>(nullptr));
 }
 
 void launch_peer_selftest(const PeerMap &pm, hipStream_t st, const double *own, double *out, unsigned seq) {
@@ -1208,7 +1230,7 @@ void launch_fused_step_ablated(int variant, const DeviceMesh &m, int threads, in
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_step_kernel<false, V>),                \
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);                      \
     hipLaunchKernelGGL((fused_step_kernel<false, V>), dim3(V == 9 ? 8 * m.n_blocks : m.n_blocks), dim3(threads), lds_bytes, st, m, d0, \
-                       dn, d1, none, cnone, V == 8 ? dbg : none, k, static_cast<const PeerMap *>(nullptr), 0u); \
+                       dn, d1, none, cnone, V == 8 ? dbg : none, k, static_cast<const PeerMap *>(nullptr), 0u, cnone); \
     break;
   switch (variant) {
     SAA_ABL(0) SAA_ABL(1) SAA_ABL(2) SAA_ABL(3) SAA_ABL(4) SAA_ABL(5) SAA_ABL(6) SAA_ABL(7) SAA_ABL(8) SAA_ABL(9)
@@ -1276,15 +1298,17 @@ void launch_force_only(const DeviceMesh &m, int threads, int lds_bytes, hipStrea
   StepConsts k{};
   hipLaunchKernelGGL(fused_step_kernel<true>, dim3(m.n_blocks), dim3(threads), lds_bytes, st, m, d, d, f,
                      static_cast<double *>(nullptr), static_cast<const double *>(nullptr),
-                     static_cast<double *>(nullptr), k, static_cast<const PeerMap *>(nullptr), 0u);
+                     static_cast<double *>(nullptr), k, static_cast<const PeerMap *>(nullptr), 0u,
+                     static_cast<const double *>(nullptr));
 }
 
 void launch_iface_finish(const DeviceMesh &m, const SharedMap &sh, hipStream_t st, const double *d0,
-                         const double *dn, double *d1, double *iface, double *hist_row, const StepConsts &k) {
+                         const double *dn, double *d1, double *iface, double *hist_row, const StepConsts &k,
+                         const double *tn_in, double *tn_out) {
   const int n = 3 * (sh.n_shared + sh.n_foreign);
-  if (n == 0) return;
-  hipLaunchKernelGGL(iface_finish_kernel, dim3((n + 255) / 256), dim3(256), 0, st, m, sh, d0, dn, d1, iface,
-                     hist_row, k);
+  if (n == 0 && tn_in == nullptr) return;  // (with a device clock the launch is also what advances it)
+  hipLaunchKernelGGL(iface_finish_kernel, dim3(((n > 0 ? n : 1) + 255) / 256), dim3(256), 0, st, m, sh, d0, dn, d1, iface,
+                     hist_row, k, tn_in, tn_out);
 }
 
 void launch_halo_overwrite(const SharedMap &sh, hipStream_t st, const double *row, double *d1, double *hist_row) {

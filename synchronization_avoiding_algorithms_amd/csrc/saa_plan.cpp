@@ -110,7 +110,9 @@ constexpr int kPairSyms[6][5] = {{0, 1, 2, 3, 4}, {0, 2, 3, 1, 4}, {0, 3, 1, 2, 
 
 // Greedy matching of the block's elements into face-sharing pairs with compatible orientation.
 // in: loc = 4 block-local node ids per element.  out: items (8 uint16 each); returns their number.
-int32_t build_items(const std::vector<uint16_t> &loc, int32_t n_elem, int32_t n_owned, std::vector<uint16_t> &items) {
+// xl / h (optional): coordinates of the block-local nodes and the mesh size, for the shape classes below.
+int32_t build_items(const std::vector<uint16_t> &loc, int32_t n_elem, int32_t n_owned, std::vector<uint16_t> &items,
+                    const double *xl = nullptr, double h = 0.0) {
   struct Face {
     uint64_t key;
     int32_t elem;
@@ -168,40 +170,134 @@ int32_t build_items(const std::vector<uint16_t> &loc, int32_t n_elem, int32_t n_
     }
     return d;
   };
+  // eligible partners of e across face k (free, same class, compatible orientation)
+  auto partner = [&](int32_t e, int k) -> int32_t {
+    const int32_t f = nb[4 * static_cast<size_t>(e) + k];
+    if (f < 0 || used[f] || interior(f) != interior(e)) return -1;
+    uint16_t A[4], B[4];
+    apex_first(e, k, A);
+    apex_first(f, nbk[4 * static_cast<size_t>(e) + k], B);
+    return compatible(A, B) ? f : -1;
+  };
+  auto degree = [&](int32_t e) {
+    int d = 0;
+    for (int k = 0; k < 4; ++k) d += partner(e, k) >= 0;
+    return d;
+  };
   items.clear();
   items.reserve(8 * static_cast<size_t>(n_elem));
   int32_t n_items = 0;
-  for (int32_t e = 0; e < n_elem; ++e) {
-    if (used[e]) continue;
-    used[e] = 1;
-    int best_k = -1, best_deg = 99;
+  auto emit_pair = [&](int32_t e, int k) {
+    const int32_t f = nb[4 * static_cast<size_t>(e) + k];
     uint16_t A[4], B[4];
+    apex_first(e, k, A);
+    apex_first(f, nbk[4 * static_cast<size_t>(e) + k], B);
+    const uint16_t it[8] = {A[0], A[1], A[2], A[3], B[0], 1, 0, 0};
+    items.insert(items.end(), it, it + 8);
+    ++n_items;
+  };
+  auto emit_single = [&](int32_t e) {
+    uint16_t it[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int a = 0; a < 4; ++a) it[a] = loc[4 * static_cast<size_t>(e) + a];
+    it[4] = it[1];  // dummy second apex: a valid LDS index that is read but never accumulated
+    items.insert(items.end(), it, it + 8);
+    ++n_items;
+  };
+  // Greedy matching in a SPATIAL order of the elements, cell by cell of a grid of the mesh size (cells in lexicographic
+  // order, the elements of a cell by the shape key of their cheapest pair): an element takes the free partner that has the
+  // fewest other options left, ties broken by shape - the vector between the two centroids and the vector between the two
+  // apices in units of half a mesh size, made independent of which element is named first.  In the order of the caller's
+  // element list (what this loop used before) a mesh numbered at random left 5 % of its elements single - 7 % more work
+  // items than the same mesh numbered cell by cell - and paired equal cells differently, so that the pattern classes of
+  // the LDS packing could not form.  Measured alternatives on the 1M-tet beams (pairs found / items in clash-free halves
+  // by construction, structured | jittered and shuffled): list order 99.9 % / 58 % | 94.8 % / 31 %; fewest-options-first
+  // (Karp-Sipser) with shape ties 99.8 % / 43 % | 99.5 % / 37 %: best matching, but its fronts run inwards from the block
+  // faces and pair equal cells differently; shape by shape, most frequent first: a third of the elements single.
+  std::vector<uint64_t> ekey(4 * static_cast<size_t>(n_elem), 0), ekey_min;
+  if (xl != nullptr && h > 0.0) {
+    auto centroid = [&](int32_t e, double c[3]) {
+      for (int j = 0; j < 3; ++j) {
+        c[j] = 0.0;
+        for (int a = 0; a < 4; ++a) c[j] += 0.25 * xl[3 * static_cast<size_t>(loc[4 * static_cast<size_t>(e) + a]) + j];
+      }
+    };
+    for (int32_t e = 0; e < n_elem; ++e)
+      for (int k = 0; k < 4; ++k) {
+        const int32_t f = nb[4 * static_cast<size_t>(e) + k];
+        if (f < 0 || f < e) continue;
+        const int kf = nbk[4 * static_cast<size_t>(e) + k];
+        double ce[3], cf[3];
+        centroid(e, ce);
+        centroid(f, cf);
+        const double *ae = xl + 3 * static_cast<size_t>(loc[4 * static_cast<size_t>(e) + k]);
+        const double *af = xl + 3 * static_cast<size_t>(loc[4 * static_cast<size_t>(f) + kf]);
+        int q[6];
+        for (int j = 0; j < 3; ++j) {
+          q[j] = static_cast<int>(std::lround(2.0 * (cf[j] - ce[j]) / h));
+          q[3 + j] = static_cast<int>(std::lround(2.0 * (af[j] - ae[j]) / h));
+        }
+        int sign = 0;
+        for (int j = 0; j < 6 && sign == 0; ++j) sign = q[j] > 0 ? 1 : (q[j] < 0 ? -1 : 0);
+        uint64_t key = 0;
+        for (int j = 0; j < 6; ++j) key = (key << 8) | static_cast<uint64_t>(((sign < 0 ? -q[j] : q[j]) + 128) & 255);
+        ekey[4 * static_cast<size_t>(e) + k] = key;
+        ekey[4 * static_cast<size_t>(f) + kf] = key;
+      }
+  }
+  std::vector<int32_t> order(n_elem);
+  std::iota(order.begin(), order.end(), 0);
+  if (xl != nullptr && h > 0.0) {
+    std::vector<uint64_t> okey(n_elem);
+    double lo[3] = {1e300, 1e300, 1e300};
+    for (int32_t e = 0; e < n_elem; ++e)
+      for (int a = 0; a < 4; ++a)
+        for (int j = 0; j < 3; ++j) lo[j] = std::min(lo[j], xl[3 * static_cast<size_t>(loc[4 * static_cast<size_t>(e) + a]) + j]);
+    for (int32_t e = 0; e < n_elem; ++e) {
+      // cell of the element: the cell of the lowest corner of its bounding box, with a quarter cell of slack for nodes
+      // that sit a little off their lattice position
+      uint64_t cell = 0;
+      for (int j = 2; j >= 0; --j) {
+        double mn = 1e300;
+        for (int a = 0; a < 4; ++a) mn = std::min(mn, xl[3 * static_cast<size_t>(loc[4 * static_cast<size_t>(e) + a]) + j]);
+        cell = (cell << 16) | static_cast<uint64_t>(static_cast<int>(std::floor((mn - lo[j]) / h + 0.25)) & 0xffff);
+      }
+      uint64_t best = ~0ull;
+      for (int k = 0; k < 4; ++k)
+        if (nb[4 * static_cast<size_t>(e) + k] >= 0) best = std::min(best, ekey[4 * static_cast<size_t>(e) + k]);
+      okey[e] = cell;
+      ekey_min.push_back(best);
+    }
+    std::sort(order.begin(), order.end(), [&](int32_t x, int32_t y) {
+      if (okey[x] != okey[y]) return okey[x] < okey[y];
+      if (ekey_min[x] != ekey_min[y]) return ekey_min[x] < ekey_min[y];
+      return x < y;
+    });
+  }
+  for (int32_t e : order) {
+    if (used[e]) continue;
+    int best_k = -1, best_deg = 99;
+    uint64_t best_key = ~0ull;
     for (int k = 0; k < 4; ++k) {
-      const int32_t f = nb[4 * static_cast<size_t>(e) + k];
-      if (f < 0 || used[f] || interior(f) != interior(e)) continue;
-      apex_first(e, k, A);
-      apex_first(f, nbk[4 * static_cast<size_t>(e) + k], B);
-      if (!compatible(A, B)) continue;
-      const int d = free_degree(f);  // take the neighbour that has the fewest other options left
-      if (d < best_deg) {
-        best_deg = d;
+      const int32_t f = partner(e, k);
+      if (f < 0) continue;
+      used[e] = 1;  // (f's options without e; the list-order variant counts every free neighbour, as it always has)
+      const int df = xl != nullptr ? degree(f) : free_degree(f);
+      used[e] = 0;
+      const uint64_t kk = ekey[4 * static_cast<size_t>(e) + k];
+      if (df < best_deg || (df == best_deg && kk < best_key)) {  // the neighbour with the fewest other options, then by shape
+        best_deg = df;
+        best_key = kk;
         best_k = k;
       }
     }
-    uint16_t it[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (best_k >= 0) {
       const int32_t f = nb[4 * static_cast<size_t>(e) + best_k];
-      used[f] = 1;
-      apex_first(e, best_k, A);
-      apex_first(f, nbk[4 * static_cast<size_t>(e) + best_k], B);
-      it[0] = A[0], it[1] = A[1], it[2] = A[2], it[3] = A[3], it[4] = B[0], it[5] = 1;
+      emit_pair(e, best_k);
+      used[e] = used[f] = 1;
     } else {
-      for (int a = 0; a < 4; ++a) it[a] = loc[4 * static_cast<size_t>(e) + a];
-      it[4] = it[1];  // dummy second apex: a valid LDS index that is read but never accumulated
-      it[5] = 0;
+      used[e] = 1;
+      emit_single(e);
     }
-    items.insert(items.end(), it, it + 8);
-    ++n_items;
   }
   return n_items;
 }
@@ -510,6 +606,7 @@ int32_t reorder_for_lds(const uint16_t *items, int32_t n_items, int32_t n_owned,
   return done;
 }
 
+
 // pi[l] = rank of owned node l of a block when its nodes are sorted lexicographically with the axes in the q-th order
 void block_axis_order(const double *xyz, const int32_t *new_to_old, int32_t n_owned, int q, std::vector<uint16_t> &pi) {
   static const int kPerm[6][3] = {{0, 1, 2}, {0, 2, 1}, {1, 0, 2}, {1, 2, 0}, {2, 0, 1}, {2, 1, 0}};
@@ -525,6 +622,79 @@ void block_axis_order(const double *xyz, const int32_t *new_to_old, int32_t n_ow
   });
   pi.resize(n_owned);
   for (int32_t r = 0; r < n_owned; ++r) pi[ord[r]] = static_cast<uint16_t>(r);
+}
+// Pseudo-lattice numbering of a block's nodes for meshes whose nodes do not sit on a lattice: the coordinates are
+// quantised with the mesh size h (cube root of six mean element volumes: the edge of the cube a Kuhn tet came from, the
+// typical node spacing of any other mesh), and a node with quantised position (i, j, k) gets a local index whose residue
+// mod 32 is that of its lexicographic lattice index i + L_i * (j + L_j * k) (L: the block's extent in cells along the
+// axis; which axis runs fastest is the variant) - as far as the 32 residue classes have room (each holds n/32 indices);
+// what does not fit takes the indices left over.  Two items that are translates of each other by whole cells then differ
+// by one constant in the residues of all their vertices, which is all the pattern classes of reorder_for_lds need: they
+// never look at the indices themselves.  Halo nodes are placed the same way (their local index is n_owned + position in
+// the halo list), so that boundary items fall into classes too.  On a jittered lattice this restores the classes of the
+// undisturbed one; on a genuinely unstructured mesh it yields them wherever the mesh is locally regular.
+struct LatticeColours {
+  double lo[3], h;
+  int ext[3], axis[3];
+  // residue class (mod 32) of a position
+  int operator()(const double *x) const {
+    int q[3];
+    for (int k = 0; k < 3; ++k) q[k] = static_cast<int>(std::floor((x[k] - lo[k]) / h + 0.5));
+    return (q[axis[0]] + ext[axis[0]] * (q[axis[1]] + ext[axis[1]] * q[axis[2]])) & 31;
+  }
+};
+LatticeColours lattice_colours(const double *xyz, const int32_t *new_to_old, int32_t n_owned, double h, int variant) {
+  static const int kPerm[6][3] = {{0, 1, 2}, {0, 2, 1}, {1, 0, 2}, {1, 2, 0}, {2, 0, 1}, {2, 1, 0}};
+  LatticeColours lc;
+  lc.h = h;
+  double hi[3] = {-1e300, -1e300, -1e300};
+  for (int k = 0; k < 3; ++k) lc.lo[k] = 1e300;
+  for (int32_t l = 0; l < n_owned; ++l)
+    for (int k = 0; k < 3; ++k) {
+      const double v = xyz[3 * static_cast<int64_t>(new_to_old[l]) + k];
+      lc.lo[k] = std::min(lc.lo[k], v);
+      hi[k] = std::max(hi[k], v);
+    }
+  for (int k = 0; k < 3; ++k) {
+    lc.ext[k] = static_cast<int>(std::floor((hi[k] - lc.lo[k]) / h + 0.5)) + 1;
+    lc.axis[k] = kPerm[variant % 6][k];
+  }
+  return lc;
+}
+// indices first..first+n-1 handed out so that index % 32 == colour wherever the class has room; pi[l] = index - first
+void assign_by_colour(const std::vector<int> &colour, int32_t first, std::vector<uint16_t> &pi) {
+  const int32_t n = static_cast<int32_t>(colour.size());
+  std::vector<int32_t> next(32);
+  for (int r = 0; r < 32; ++r) next[r] = first + ((r - first) % 32 + 32) % 32;  // smallest index >= first with residue r
+  pi.assign(n, 0xffff);
+  std::vector<int32_t> spill;
+  for (int32_t l = 0; l < n; ++l) {
+    int32_t &i = next[colour[l]];
+    if (i < first + n) {
+      pi[l] = static_cast<uint16_t>(i - first);
+      i += 32;
+    } else {
+      spill.push_back(l);
+    }
+  }
+  size_t j = 0;
+  for (int r = 0; r < 32 && j < spill.size(); ++r)
+    for (int32_t i = next[r]; i < first + n && j < spill.size(); i += 32) pi[spill[j++]] = static_cast<uint16_t>(i - first);
+}
+void block_lattice_order(const double *xyz, const int32_t *new_to_old, int32_t n_owned, double h, int variant,
+                         std::vector<uint16_t> &pi) {
+  const LatticeColours lc = lattice_colours(xyz, new_to_old, n_owned, h, variant);
+  std::vector<int> colour(n_owned);
+  for (int32_t l = 0; l < n_owned; ++l) colour[l] = lc(xyz + 3 * static_cast<int64_t>(new_to_old[l]));
+  assign_by_colour(colour, 0, pi);
+}
+// halo vertex slots of `n` items renamed through pih (old -> new position in the halo list)
+void relabel_halo(uint16_t *items, int32_t n, int32_t n_owned, const std::vector<uint16_t> &pih) {
+  for (int32_t i = 0; i < n; ++i) {
+    uint16_t *it = items + 8 * static_cast<size_t>(i);
+    for (int a = 0; a < 5; ++a)
+      if (it[a] >= n_owned) it[a] = static_cast<uint16_t>(n_owned + pih[it[a] - n_owned]);
+  }
 }
 // owned vertex slots of `n` items renamed through pi (halo slots keep their numbers)
 void relabel_owned(uint16_t *items, int32_t n, int32_t n_owned, const std::vector<uint16_t> &pi) {
@@ -694,17 +864,52 @@ bool build_once(int32_t n_nodes, int32_t n_elems, const double *xyz, const int32
   const unsigned n_thr = static_cast<unsigned>(std::min<int64_t>(hw, std::max<int32_t>(1, n_blocks / 8)));
   std::vector<PackStats> stats(n_thr);
   std::vector<std::vector<uint16_t>> block_perm(n_blocks);  // non-empty: old -> new local index of the block's owned nodes
+  std::vector<std::vector<uint16_t>> block_halo_perm(n_blocks);  // non-empty: old -> new position in the block's halo list
+  const char *shp_env = getenv("SAA_PLAN_SHAPE_PAIRS");
+  const bool shape_pairs = !(shp_env && shp_env[0] == '0');
+  const char *lat_env = getenv("SAA_PLAN_LATTICE_ORDERS");
+  const bool lattice_orders = !(lat_env && lat_env[0] == '0');
+  std::atomic<int32_t> renumbered{0};
   const char *alt_env = getenv("SAA_PLAN_FIXED_AXES");
   const bool alt_axes = !(alt_env && alt_env[0] == '1');
   std::atomic<int32_t> next{0};
   auto work = [&](unsigned t) {
-    std::vector<uint16_t> items, part_a, part_b, part_q, loc_b, trial, pi;
+    std::vector<uint16_t> items, items_s, part_a, part_b, part_q, loc_b, trial, pi;
+    std::vector<double> xl;
     std::vector<char> interior;
     for (int32_t b = next.fetch_add(1); b < n_blocks; b = next.fetch_add(1)) {
       const BlockDesc &d = plan.blocks[b];
       const int32_t ne = static_cast<int32_t>(off[b + 1] - off[b]);
       loc_b.assign(loc.begin() + 4 * off[b], loc.begin() + 4 * off[b + 1]);
-      const int32_t ni = build_items(loc_b, ne, d.n_owned, items);
+      // coordinates of the block-local nodes and the block's mesh size (cube root of six mean element volumes)
+      xl.resize(3 * static_cast<size_t>(d.n_owned + d.n_halo));
+      for (int32_t l = 0; l < d.n_owned + d.n_halo; ++l) {
+        const int32_t g = l < d.n_owned ? d.node_start + l : plan.halo_ids[d.halo_off + (l - d.n_owned)];
+        for (int k = 0; k < 3; ++k) xl[3 * static_cast<size_t>(l) + k] = xyz[3 * static_cast<int64_t>(plan.new_to_old[g]) + k];
+      }
+      double h_mesh = 0.0;
+      {
+        double vol = 0.0;
+        for (int32_t e = 0; e < ne; ++e) {
+          const double *x0 = &xl[3 * static_cast<size_t>(loc_b[4 * e])], *x1 = &xl[3 * static_cast<size_t>(loc_b[4 * e + 1])],
+                       *x2 = &xl[3 * static_cast<size_t>(loc_b[4 * e + 2])], *x3 = &xl[3 * static_cast<size_t>(loc_b[4 * e + 3])];
+          const double a[3] = {x1[0] - x0[0], x1[1] - x0[1], x1[2] - x0[2]}, bb[3] = {x2[0] - x0[0], x2[1] - x0[1], x2[2] - x0[2]},
+                       c[3] = {x3[0] - x0[0], x3[1] - x0[1], x3[2] - x0[2]};
+          vol += std::fabs(a[0] * (bb[1] * c[2] - bb[2] * c[1]) - a[1] * (bb[0] * c[2] - bb[2] * c[0]) + a[2] * (bb[0] * c[1] - bb[1] * c[0]));
+        }
+        h_mesh = ne > 0 ? std::cbrt(vol / ne) : 0.0;  // |detJ| = 6 V
+      }
+      // pairing in the order of the caller's element list, and in the spatial order; the latter when it leaves at least
+      // 1 % fewer items (a mesh numbered cell by cell pairs best as it comes: 99.9 % of the elements of the structured
+      // beams, against 97.8 % in the spatial order)
+      int32_t ni = build_items(loc_b, ne, d.n_owned, items);
+      if (shape_pairs && h_mesh > 0.0) {
+        const int32_t ni_s = build_items(loc_b, ne, d.n_owned, items_s, xl.data(), h_mesh);
+        if (100 * static_cast<int64_t>(ni_s) < 99 * static_cast<int64_t>(ni)) {
+          items.swap(items_s);
+          ni = ni_s;
+        }
+      }
       // interior items (every real vertex owned) first: they can run before the halo records arrive
       std::vector<uint16_t> &out = block_items[b];
       out.resize(8 * static_cast<size_t>(ni));
@@ -736,8 +941,12 @@ bool build_once(int32_t n_nodes, int32_t n_elems, const double *xyz, const int32
         int best_q = 0;
         int64_t best_constr = st_in.by_construction;
         std::vector<uint16_t> best_pi;
-        for (int q = 1; q < 6; ++q) {
-          block_axis_order(xyz, plan.new_to_old.data() + d.node_start, d.n_owned, q, pi);
+        // (orders 6..11: pseudo-lattice numberings, block_lattice_order)
+        for (int q = 1; q < (lattice_orders && h_mesh > 0.0 ? 12 : 6); ++q) {
+          if (q < 6)
+            block_axis_order(xyz, plan.new_to_old.data() + d.node_start, d.n_owned, q, pi);
+          else
+            block_lattice_order(xyz, plan.new_to_old.data() + d.node_start, d.n_owned, h_mesh, q - 6, pi);
           trial.assign(out.begin(), out.begin() + 8 * static_cast<size_t>(n_in));
           relabel_owned(trial.data(), n_in, d.n_owned, pi);
           PackStats st_q;
@@ -754,10 +963,21 @@ bool build_once(int32_t n_nodes, int32_t n_elems, const double *xyz, const int32
           m_in = reorder_for_lds(out.data(), n_in, d.n_owned, pad, part_a, st_in);
           block_perm[b] = best_pi;
         }
+        if (best_q >= 6 && d.n_halo > 0) {  // halo list in the same pseudo-lattice: the boundary items form classes too
+          const LatticeColours lc = lattice_colours(xyz, plan.new_to_old.data() + d.node_start, d.n_owned, h_mesh, best_q - 6);
+          std::vector<int> colour(d.n_halo);
+          for (int32_t hh = 0; hh < d.n_halo; ++hh)
+            colour[hh] = lc(xyz + 3 * static_cast<int64_t>(plan.new_to_old[plan.halo_ids[d.halo_off + hh]]));
+          assign_by_colour(colour, d.n_owned, block_halo_perm[b]);
+          relabel_halo(out.data() + 8 * static_cast<size_t>(n_in), ni - n_in, d.n_owned, block_halo_perm[b]);
+          ++renumbered;
+        }
       }
-      stats[t].add(st_in);
+      PackStats st_bd;
       const int32_t m_bd = reorder_for_lds(out.data() + 8 * static_cast<size_t>(n_in), ni - n_in, d.n_owned, pad,
-                                           part_b, stats[t]);
+                                           part_b, st_bd);
+      stats[t].add(st_in);
+      stats[t].add(st_bd);
       out = part_a;
       out.insert(out.end(), part_b.begin(), part_b.end());
       n_interior[b] = m_in;
@@ -771,6 +991,16 @@ bool build_once(int32_t n_nodes, int32_t n_elems, const double *xyz, const int32
     work(0);
     for (auto &th : pool) th.join();
   }
+  // blocks that re-ordered their halo list
+  for (int32_t b = 0; b < n_blocks; ++b) {
+    const std::vector<uint16_t> &ph = block_halo_perm[b];
+    if (ph.empty()) continue;
+    int32_t *seg = plan.halo_ids.data() + plan.blocks[b].halo_off;
+    std::vector<int32_t> moved(ph.size());
+    for (size_t h = 0; h < ph.size(); ++h) moved[ph[h]] = seg[h];
+    std::copy(moved.begin(), moved.end(), seg);
+  }
+  if (getenv("SAA_PLAN_DEBUG")) fprintf(stderr, "plan: %d of %d blocks took a pseudo-lattice numbering\n", renumbered.load(), n_blocks);
   // blocks that changed their internal order: the numbering (and with it every halo list that names their nodes) follows
   {
     int32_t n_changed = 0;
@@ -823,6 +1053,8 @@ bool build_once(int32_t n_nodes, int32_t n_elems, const double *xyz, const int32
     tot.by_construction += st.by_construction;
   }
   plan.lds_conflict_factor = tot.read_cnt ? tot.read_mult / tot.read_cnt : 1.0;
+  plan.lds_atomic_conflict_factor = tot.atomic_cnt ? tot.atomic_mult / tot.atomic_cnt : 1.0;
+  plan.n_by_construction = tot.by_construction;
   if (getenv("SAA_PLAN_DEBUG")) {
     // distribution of the per-block work (items) and of its interior / boundary split
     int32_t mn = INT32_MAX, mx = 0, mxi = 0, mxb = 0;

@@ -51,7 +51,9 @@ struct Plan {
   // q 24, r 36, b 48), flag in bits 60-61 - 8 bytes of connectivity per TWO elements.
   std::vector<uint64_t> conn_packed;
   int64_t n_items = 0, n_pairs = 0;
-  double lds_conflict_factor = 1.0; // mean over (half-wave, vertex slot) of the worst bank multiplicity
+  double lds_conflict_factor = 1.0; // mean over (ds_read_b128 lane group, vertex slot) of the worst bank multiplicity
+  double lds_atomic_conflict_factor = 1.0;  // the same for the ds_add_f64 of a half-wave (owned vertices only)
+  int64_t n_by_construction = 0;    // item slots in half-waves that are clash-free by construction (pattern classes)
   int32_t max_owned = 0, max_local = 0;
   int64_t n_elem_copies = 0, n_halo_total = 0;
 };

@@ -171,35 +171,28 @@ hipError_t setup_fields(int32_t n_nodes, int32_t n_elems, const double *xyz_host
 
 // ---------------------------------------------------------------------------------------------
 // Device-to-device copy rate of this GPU: the practical HBM ceiling next to the nominal 8 TB/s.
-// 16 bytes per lane (global_load_dwordx4 / global_store_dwordx4), grid-stride, 8 workgroups of 256 threads per CU, four
-// independent loads in flight per lane - the "float4 copy" MI355X_MICROARCH.md quotes 6.29 TB/s for.
+// 16 bytes per lane (global_load_dwordx4 / global_store_dwordx4), ONE element per thread, as many workgroups as it takes: the
+// shape that reaches the 6.2 TB/s MI355X_MICROARCH.md quotes for a float4 copy (measured on MI355X, 1 GiB -> 1 GiB, TB/s:
+// this 6.22; four elements per thread from one contiguous chunk 5.99, eight 5.60; grid-stride loops of 2048-8192
+// workgroups 4.4-4.9; hipMemcpyDtoD 5.49; torch's copy_ 4.8-5.1 - tools/copy_bw.hip, profiles/r03_copy_shapes.txt).
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) copy16_kernel(const double2 *__restrict__ src, double2 *__restrict__ dst, int64_t n) {
-  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
-  int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-  for (; i + 3 * stride < n; i += 4 * stride) {
-    const double2 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
-    dst[i] = a;
-    dst[i + stride] = b;
-    dst[i + 2 * stride] = c;
-    dst[i + 3 * stride] = d;
-  }
-  for (; i < n; i += stride) dst[i] = src[i];
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (i < n) dst[i] = src[i];
 }
 
 hipError_t copy_bandwidth(int device, int64_t n_bytes, int reps, double *bytes_per_s) {
   Scratch sc;
   const int64_t n = n_bytes / 16;
   double2 *a, *b;
-  int cus = 0;
-  SETUP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
+  (void)device;
   SETUP_TRY(sc.alloc(&a, static_cast<size_t>(n)));
   SETUP_TRY(sc.alloc(&b, static_cast<size_t>(n)));
   SETUP_TRY(hipMemset(a, 0x3c, static_cast<size_t>(n) * 16));  // finite, non-zero doubles
   hipEvent_t e0, e1;
   SETUP_TRY(hipEventCreate(&e0));
   SETUP_TRY(hipEventCreate(&e1));
-  const dim3 grid(static_cast<unsigned>(8 * (cus > 0 ? cus : 256)));
+  const dim3 grid(static_cast<unsigned>((n + 255) / 256));
   for (int r = 0; r < 2; ++r) hipLaunchKernelGGL(copy16_kernel, grid, dim3(256), 0, nullptr, a, b, n);  // warm
   hipError_t e = hipEventRecord(e0, nullptr);
   for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(copy16_kernel, grid, dim3(256), 0, nullptr, a, b, n);

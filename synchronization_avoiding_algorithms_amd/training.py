@@ -221,11 +221,12 @@ def windows_from_history(hist, filter_size, n_past, n_future, cut_off=1.0):
 
 
 def fit_windows(X, Y, hidden_size=50, batch_size=10, learning_rate=5e-4, decay=0.998, lr_min=5e-7, T_portion=0.75,
-                num_epochs=None, max_seconds=None, generator=None, verbose=False, rank=0):
+                num_epochs=None, max_seconds=None, generator=None, verbose=False, rank=0, log=None):
     """The training loop of ``Model_training.py:60-139`` on already scaled windows ``X (groups, n_past, in)``,
     ``Y (groups, n_future, in)``: Adam, learning rate ``decay**epoch``, random ``T_portion`` training split, shuffled
     mini-batches, validation on the rest; on a GPU the optimiser step is replayed as a HIP graph.  Stops after
-    ``num_epochs`` (default: until the rate reaches ``lr_min``, ``:65``) or ``max_seconds`` of wall time.
+    ``num_epochs`` (default: until the rate reaches ``lr_min``, ``:65``) or ``max_seconds`` of wall time.  ``verbose``:
+    the reference's progress line every 50 epochs (rank 0), to ``log`` (default: stdout).
     Returns ``(model, train_loss, validation_loss)`` (per-epoch means)."""
     import time
 
@@ -265,7 +266,7 @@ def fit_windows(X, Y, hidden_size=50, batch_size=10, learning_rate=5e-4, decay=0
         test_loss.append(lv / max(len(vb), 1))
         if verbose and rank == 0 and epoch % 50 == 0:
             print("Epoch: %d, mse training loss: %1.5e, R2 accuracy: %.3f, lr=%g"
-                  % (epoch, train_loss[-1], r2 / len(tb), float(optimizer.param_groups[0]["lr"])))
+                  % (epoch, train_loss[-1], r2 / len(tb), float(optimizer.param_groups[0]["lr"])), file=log, flush=True)
         scheduler.step()
         if max_seconds is not None and time.time() - t0 > max_seconds:
             break

@@ -80,7 +80,7 @@ def test_headline_at_the_drivers_flags_is_warm():
     roof = out["roofline"]
     assert roof["launches_timed"] >= 10 and 0.3 < roof["frac"] < 1.5
     # the practical HBM ceiling comes from the library's own 16-byte-per-lane copy kernel (the guide: 6.29 TB/s)
-    assert 4500 < roof["measured_copy_GBps"] < 8000, roof["measured_copy_GBps"]
+    assert 5000 < roof["measured_copy_GBps"] < 8000, roof["measured_copy_GBps"]
     assert out["legs"]["roofline"] == "done" and out["legs"]["cpu_baseline"].startswith("skipped")
     kernel_rate = 1028850 / (roof["us_per_step"] * 1e-6)
     assert out["value"] > kernel_rate / 1.5, (out["value"], kernel_rate)

@@ -153,8 +153,30 @@ def test_native_rccl_exchange_single_rank(beam_coarse):
     dof = (3 * shared[:, None] + np.arange(3)[None, :]).ravel()
     assert np.array_equal(hist[199].cpu().numpy(), b[dof, 0])
     assert float(iface[24:].abs().max()) == 0.0  # foreign slots re-zeroed
+    # without history rows the same steps run as replayed HIP graphs (three steps per graph, the clock and with it the
+    # ramp in device memory): 2 x 100 more steps - graphs of both rotation phases plus eager remainders - against plain
+    # steps and against the eager route of a second handle
+    eager = saa.HipExplicitSolver(*args, shared_local=shared, shared_slots=np.arange(8, dtype=np.int32)[::-1].copy(),
+                                  n_global_shared=10)
+    iface2 = torch.zeros(30, dtype=torch.float64, device="cuda")
+    eager.set_interface_buffer(iface2)
+    eager.set_stream(torch.cuda.current_stream().cuda_stream)
+    eager.comm_init(eager.comm_unique_id(), 0, 1)
+    os.environ["SAA_SYNCED_GRAPH"] = "0"
+    try:
+        eager.step_synced(400)
+    finally:
+        del os.environ["SAA_SYNCED_GRAPH"]
+    plain.step(200)
+    synced.step_synced(100)
+    synced.step_synced(100)
+    torch.cuda.synchronize()
+    (a, an, ta), (b, bn, tb), (c, cn, tc) = plain.get_state(), synced.get_state(), eager.get_state()
+    assert ta == tb == tc  # the host's clock advanced exactly like the device's
+    assert rel_l2(b, a) < 1e-13 and rel_l2(bn, an) < 1e-13 and rel_l2(b, c) < 1e-13 and rel_l2(bn, cn) < 1e-13
     plain.close()
     synced.close()
+    eager.close()
 
 
 def _nccl_single_worker(rank, world, port, out_dir):

@@ -31,3 +31,4 @@ def test_step_kernels_fit_their_register_budget_without_spills():
         # scalar registers: 112 is the allocation band the grid sizing of the resident kernel assumes (saa_kernels.hip:
         # persistent_max_blocks, MI355X_MICROARCH.md "Residency")
         assert r["sgpr"] <= 112, (name, r)
+

@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""A/B of step-kernel builds on one GPU box: every library given on the command line steps the same meshes in the same
+process order, alternating, so that clocks and box are the same for all of them.
+
+    python tools/ab.py name=path/to/lib.so [name=...] [--cases=resident19,fused19,fused38] [--rounds=3]
+
+Cases: resident<n> (saa_step through the resident kernel, 1000-step launches), fused<n> (one launch per step).
+Each (library, case) runs in a child process (a library is loaded once per process); prints us/step per round and the
+median."""
+import json
+import os
+import subprocess
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHILD = r"""
+import sys, json, os
+sys.path.insert(0, %r)
+sys.argv = ['bench.py']
+import numpy as np
+from bench import build_rank_solver, bench_mesh
+case, kind = sys.argv_case
+n = int(''.join(ch for ch in case if ch.isdigit()))
+mesh = bench_mesh(n, kind)
+sol, lay, _, _ = build_rank_solver(mesh, 1, 0, 0)
+resident = case.startswith('resident')
+if not resident:
+    sol.set_resident_kernel(False)
+assert sol.resident_kernel_info()['capable'] == resident, sol.resident_kernel_info()
+steps = 4000 if resident else (1000 if n < 30 else 300)
+sol.time_steps(steps)
+out = [1e3 * sol.time_steps(steps) / steps for _ in range(3)]
+d0 = sol.get_state()[0]
+print(json.dumps({'us': out, 'norm': float(np.linalg.norm(d0)), 'plan': sol.plan_stats()}))
+"""
+
+
+def main():
+    libs, cases, rounds, kind = [], ["resident19", "fused19", "fused38"], 2, "structured"
+    for a in sys.argv[1:]:
+        if a.startswith("--cases="):
+            cases = a.split("=", 1)[1].split(",")
+        elif a.startswith("--rounds="):
+            rounds = int(a.split("=", 1)[1])
+        elif a.startswith("--mesh="):
+            kind = a.split("=", 1)[1]
+        else:
+            name, path = a.split("=", 1)
+            libs.append((name, os.path.abspath(path)))
+    res = {}
+    for case in cases:
+        for r in range(rounds):
+            for name, path in libs:
+                env = dict(os.environ, SAA_LIB_PATH=path)
+                code = CHILD.replace("sys.argv_case", repr((case, kind))) % REPO
+                p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+                if p.returncode != 0:
+                    print(f"{case} {name}: FAILED\n{p.stderr[-1500:]}", flush=True)
+                    continue
+                rec = json.loads(p.stdout.strip().splitlines()[-1])
+                res.setdefault((case, name), []).extend(rec["us"])
+                print(f"{case:12s} {name:10s} round {r}: " + " ".join(f"{u:8.3f}" for u in rec["us"]) +
+                      f"  us/step   |d|={rec['norm']:.12e}  conflict {rec['plan']['lds_conflict_factor']:.3f}", flush=True)
+    print()
+    for (case, name), us in res.items():
+        us = sorted(us)
+        print(f"{case:12s} {name:10s} median {us[len(us) // 2]:8.3f}  min {us[0]:8.3f} us/step")
+
+
+if __name__ == "__main__":
+    main()

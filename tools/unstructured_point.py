@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Diagnostic: what an unstructured mesh of the bench's size costs - the 1 028 850-tet beam with jittered nodes and
-shuffled node / element numbering (no lattice for the clash-free LDS packing to find; the greedy stage does all the work)."""
+shuffled node / element numbering (bench.py --mesh jittered uses the same kind of mesh).  SAA_PLAN_SHAPE_PAIRS=0
+SAA_PLAN_LATTICE_ORDERS=0 switch the plan back to round 2's behaviour (elements paired in list order, block nodes numbered
+by exact coordinates: no pattern classes on such a mesh, the greedy stage does all the work)."""
 import os
 import sys
 import time
@@ -24,6 +26,8 @@ for name, mesh in (("structured", structured_beam(n)), ("jittered + shuffled", _
     sol.time_steps(1000)
     us = np.mean([sol.time_steps(1000) for _ in range(5)])
     st = sol.plan_stats()
-    print(f"{name:20s}: set-up {t1 - t0:.1f} s, {us:.2f} us/step, conflict factor {st['lds_conflict_factor']:.3f}, element copies "
-          f"{st['n_elem_copies'] / len(mesh.tets):.3f}x, blocks {st['n_blocks']}, resident {sol.resident_kernel_info()['capable']}", flush=True)
+    print(f"{name:20s}: set-up {t1 - t0:.1f} s, {us:.2f} us/step, conflict factor reads {st['lds_conflict_factor']:.3f} atomics "
+          f"{st['lds_atomic_conflict_factor']:.3f}, element copies {st['n_elem_copies'] / len(mesh.tets):.3f}x in {st['n_items']} "
+          f"items ({st['n_pairs']} pairs, {st['n_by_construction']} in clash-free halves by construction), blocks "
+          f"{st['n_blocks']}, resident {sol.resident_kernel_info()['capable']}", flush=True)
     sol.close()
