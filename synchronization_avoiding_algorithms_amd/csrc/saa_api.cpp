@@ -836,8 +836,8 @@ int saa_create(const saa_problem *pb, saa_solver **out) {
     return SAA_E_HIP;
   }
   s->mesh.slot_sidx = s->slot_sidx.p;
-  s->mesh.lambda_ = pb->lambda_;
-  s->mesh.mu = pb->mu;
+  s->mesh.lambda6 = pb->lambda_ / 6.0;
+  s->mesh.mu6 = pb->mu / 6.0;
   s->mesh.n_blocks = static_cast<int32_t>(plan.blocks.size());
   s->mesh.n_nodes = n;
   s->mesh.max_local = plan.max_local;

@@ -24,7 +24,7 @@ struct DeviceMesh {
                             // (0,-fz,-fz)*V/4, commons.py:35-41 - else nullptr: saves 16 B per node and step
   const int32_t *tag;  // (n_nodes)
   const int32_t *slot_sidx;  // (n_global_shared) interface slot -> index in the caller's shared list, -1 if foreign
-  double lambda_, mu;
+  double lambda6, mu6;  // Lame parameters / 6: the factor of the element volume detJ/6 (tet_core)
   int32_t n_blocks, n_nodes, max_local, max_owned;
 };
 

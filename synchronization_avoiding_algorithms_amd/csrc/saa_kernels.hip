@@ -51,7 +51,7 @@ __device__ __forceinline__ double cd_update_dof(double f_int, double f_pre, doub
 }
 
 // Internal force of one linear tet on its nodes 1..3 (node 0 gets minus their sum).
-// x*, u*: coordinates / displacements of the 4 nodes.  lam, mu: Lame parameters.
+// x*, u*: coordinates / displacements of the 4 nodes.  lam6, mu6: Lame parameters divided by 6.
 struct Vec3 {
   double x, y, z;
 };
@@ -60,42 +60,66 @@ __device__ __forceinline__ Vec3 cross(const Vec3 &a, const Vec3 &b) {
   return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
 }
 
-__device__ __forceinline__ void tet_forces(const Vec3 &x0, const Vec3 &x1, const Vec3 &x2, const Vec3 &x3,
-                                           const Vec3 &u0, const Vec3 &u1, const Vec3 &u2, const Vec3 &u3,
-                                           double lam, double mu, Vec3 &f1, Vec3 &f2, Vec3 &f3) {
+// Core of tet_forces on the edge vectors e_a = x_a - x_0, the displacement differences w_a = u_a - u_0 and the first
+// cofactor row c1 = e2 x e3, which the two tets of a work item share up to its sign (see item_forces).
+// lam6, mu6: the Lame parameters divided by 6 (DeviceMesh: the host divides once).
+__device__ __forceinline__ void tet_core(const Vec3 &e1, const Vec3 &e2, const Vec3 &e3, const Vec3 &c1, const Vec3 &w1,
+                                         const Vec3 &w2, const Vec3 &w3, double lam6, double mu6, Vec3 &f1, Vec3 &f2, Vec3 &f3) {
   // J columns are the edges x_a - x_0 (Shape_function_Deriv.py:60-67); gradN_a = c_a / detJ with
   // c_1 = e2 x e3, c_2 = e3 x e1, c_3 = e1 x e2 (rows of adj J), detJ = e1 . c_1 (signed, :93).
-  const Vec3 e1 = sub(x1, x0), e2 = sub(x2, x0), e3 = sub(x3, x0);
-  const Vec3 c1 = cross(e2, e3), c2 = cross(e3, e1), c3 = cross(e1, e2);
+  const Vec3 c2 = cross(e3, e1), c3 = cross(e1, e2);
   const double det = e1.x * c1.x + e1.y * c1.y + e1.z * c1.z;
-  // s = (detJ/6)/detJ^2 = 1/(6 detJ): v_rcp_f64 (~26 bits) + two Newton steps reach fp64 round-off in
-  // 5 instructions instead of the ~11 (several quarter-rate) of the IEEE division sequence.
-  const double dd = 6.0 * det;
-  double s = __builtin_amdgcn_rcp(dd);
-  s = __builtin_fma(s, __builtin_fma(-dd, s, 1.0), s);
-  s = __builtin_fma(s, __builtin_fma(-dd, s, 1.0), s);
-  const Vec3 w1 = sub(u1, u0), w2 = sub(u2, u0), w3 = sub(u3, u0);
-  // H' = detJ * grad u = sum_a w_a (x) c_a
+  // r = 1/detJ: v_rcp_f64 (~27 bits) and ONE Newton step - the error after it is the square of the seed's, 2^-54, i.e.
+  // r is within an ulp or two, the same class as the rounding of every other operation here (a second step, used until
+  // round 3, bought nothing measurable in any parity figure); the factor 1/6 of s = (detJ/6)/detJ^2 sits in lam6 / mu6.
+  // Three instructions where the IEEE division sequence takes eleven, several of them quarter-rate.
+  double r = __builtin_amdgcn_rcp(det);
+  r = __builtin_fma(r, __builtin_fma(-det, r, 1.0), r);
+  // H' = detJ * grad u = sum_a w_a (x) c_a; the off-diagonal entries are only needed as the sums h_ij + h_ji of the
+  // symmetric strain, each accumulated as ONE chain of six products
   const double h00 = w1.x * c1.x + w2.x * c2.x + w3.x * c3.x;
-  const double h01 = w1.x * c1.y + w2.x * c2.y + w3.x * c3.y;
-  const double h02 = w1.x * c1.z + w2.x * c2.z + w3.x * c3.z;
-  const double h10 = w1.y * c1.x + w2.y * c2.x + w3.y * c3.x;
   const double h11 = w1.y * c1.y + w2.y * c2.y + w3.y * c3.y;
-  const double h12 = w1.y * c1.z + w2.y * c2.z + w3.y * c3.z;
-  const double h20 = w1.z * c1.x + w2.z * c2.x + w3.z * c3.x;
-  const double h21 = w1.z * c1.y + w2.z * c2.y + w3.z * c3.y;
   const double h22 = w1.z * c1.z + w2.z * c2.z + w3.z * c3.z;
+  const double g01 = w1.x * c1.y + w2.x * c2.y + w3.x * c3.y + w1.y * c1.x + w2.y * c2.x + w3.y * c3.x;
+  const double g02 = w1.x * c1.z + w2.x * c2.z + w3.x * c3.z + w1.z * c1.x + w2.z * c2.x + w3.z * c3.x;
+  const double g12 = w1.y * c1.z + w2.y * c2.z + w3.y * c3.z + w1.z * c1.y + w2.z * c2.y + w3.z * c3.y;
   // sigma' * s with sigma = lam tr(eps) I + 2 mu eps (commons.py:25-31, Voigt xx,yy,zz,yz,xz,xy)
-  const double ls = lam * s, ms = mu * s, ms2 = ms + ms;
+  const double ls = lam6 * r, ms = mu6 * r, ms2 = ms + ms;
   const double ltr = ls * (h00 + h11 + h22);
   const double sxx = ltr + ms2 * h00, syy = ltr + ms2 * h11, szz = ltr + ms2 * h22;
-  const double syz = ms * (h12 + h21), sxz = ms * (h02 + h20), sxy = ms * (h01 + h10);
+  const double syz = ms * g12, sxz = ms * g02, sxy = ms * g01;
   f1 = {sxx * c1.x + sxy * c1.y + sxz * c1.z, sxy * c1.x + syy * c1.y + syz * c1.z,
         sxz * c1.x + syz * c1.y + szz * c1.z};
   f2 = {sxx * c2.x + sxy * c2.y + sxz * c2.z, sxy * c2.x + syy * c2.y + syz * c2.z,
         sxz * c2.x + syz * c2.y + szz * c2.z};
   f3 = {sxx * c3.x + sxy * c3.y + sxz * c3.z, sxy * c3.x + syy * c3.y + syz * c3.z,
         sxz * c3.x + syz * c3.y + szz * c3.z};
+}
+__device__ __forceinline__ void tet_forces(const Vec3 &x0, const Vec3 &x1, const Vec3 &x2, const Vec3 &x3,
+                                           const Vec3 &u0, const Vec3 &u1, const Vec3 &u2, const Vec3 &u3,
+                                           double lam6, double mu6, Vec3 &f1, Vec3 &f2, Vec3 &f3) {
+  const Vec3 e1 = sub(x1, x0), e2 = sub(x2, x0), e3 = sub(x3, x0);
+  tet_core(e1, e2, e3, cross(e2, e3), sub(u1, u0), sub(u2, u0), sub(u3, u0), lam6, mu6, f1, f2, f3);
+}
+// The two tets of a work item, A = (p; a, r, q) and B = (p; b, q, r), evaluated from their common vertex p: the face
+// edges r - p and q - p, the displacement differences along them and their cross product are computed once - B's first
+// cofactor row (q - p) x (r - p) is A's (r - p) x (q - p) with the sign changed.
+struct PairShared {
+  Vec3 er, eq, wr, wq, c;  // r - p, q - p, u_r - u_p, u_q - u_p, (r - p) x (q - p)
+};
+__device__ __forceinline__ PairShared pair_shared(const Vec3 &xp, const Vec3 &xq, const Vec3 &xr, const Vec3 &up,
+                                                  const Vec3 &uq, const Vec3 &ur) {
+  const Vec3 er = sub(xr, xp), eq = sub(xq, xp);
+  return {er, eq, sub(ur, up), sub(uq, up), cross(er, eq)};
+}
+__device__ __forceinline__ void tet_a_forces(const PairShared &g, const Vec3 &xp, const Vec3 &xa, const Vec3 &up,
+                                             const Vec3 &ua, double lam6, double mu6, Vec3 &fa, Vec3 &fr, Vec3 &fq) {
+  tet_core(sub(xa, xp), g.er, g.eq, g.c, sub(ua, up), g.wr, g.wq, lam6, mu6, fa, fr, fq);
+}
+__device__ __forceinline__ void tet_b_forces(const PairShared &g, const Vec3 &xp, const Vec3 &xb, const Vec3 &up,
+                                             const Vec3 &ub, double lam6, double mu6, Vec3 &fb, Vec3 &fq, Vec3 &fr) {
+  const Vec3 nc = {-g.c.x, -g.c.y, -g.c.z};
+  tet_core(sub(xb, xp), g.eq, g.er, nc, sub(ub, up), g.wq, g.wr, lam6, mu6, fb, fq, fr);
 }
 
 typedef __attribute__((address_space(3))) double lds_double;
@@ -176,7 +200,7 @@ struct NoHook {
 // `mid` runs once per call, half-way through the item (after tet A): the resident kernel issues its halo loads there.
 template <int ABLATE, typename Hook = NoHook, bool ALL_OWNED = false>
 __device__ __forceinline__ void item_forces(const uint2 w, const double *rec, double *acc, int n_owned,
-                                            double lam, double mu, int tid, double &sink, unsigned long long *T = nullptr,
+                                            double lam6, double mu6, int tid, double &sink, unsigned long long *T = nullptr,
                                             Hook mid = Hook()) {
   Item it = unpack(w);
   if (it.null) {  // idle lane left by the LDS packing (saa_plan.cpp)
@@ -191,9 +215,9 @@ __device__ __forceinline__ void item_forces(const uint2 w, const double *rec, do
     const double t = 1.0 + 1e-3 * tid + sink;
     Vec3 g1, g2, g3;
     tet_forces({t, 0.1, 0.2}, {1.1 * t, 0.3, 0.1}, {0.2, t, 0.3}, {0.1, 0.2, 1.3 * t}, {t, t, 0}, {0, t, t}, {t, 0, t},
-               {t, t, t}, lam, mu, fa, fr, fq);
+               {t, t, t}, lam6, mu6, fa, fr, fq);
     tet_forces({t, 0.1, 0.2}, {1.2 * t, 0.3, 0.1}, {0.1, 0.2, 1.3 * t}, {0.2, t, 0.3}, {t, t, 0}, {0, 2 * t, t}, {t, t, t},
-               {t, 0, t}, lam, mu, g1, g2, g3);
+               {t, 0, t}, lam6, mu6, g1, g2, g3);
     sink += fa.x + fa.y + fa.z + fr.x + fr.y + fr.z + fq.x + fq.y + fq.z + g1.x + g1.y + g1.z + g2.x + g2.y + g2.z +
             g3.x + g3.y + g3.z;
     mid();
@@ -202,6 +226,7 @@ __device__ __forceinline__ void item_forces(const uint2 w, const double *rec, do
   unsigned long long t0 = 0, t1 = 0;
   if (ABLATE == 8) t0 = stamp();
   const Rec rp = load_rec(rec, it.p), rq = load_rec(rec, it.q), rr = load_rec(rec, it.r);
+  PairShared pg;
   {
     const Rec ra = load_rec(rec, it.a);
     if (ABLATE == 8) {
@@ -212,8 +237,8 @@ __device__ __forceinline__ void item_forces(const uint2 w, const double *rec, do
       fa = add3(ra.x, ra.u); fp = add3(rp.x, rp.u); fq = add3(rq.x, rq.u); fr = add3(rr.x, rr.u);
     } else {
       // A as (p; a, r, q): forces on a, r, q; p gets minus their sum
-      tet_forces(rp.x, ra.x, rr.x, rq.x, rp.u, ra.u, rr.u, rq.u, lam, mu, fa, fr, fq);
-      fp = neg_sum3(fa, fr, fq);
+      pg = pair_shared(rp.x, rq.x, rr.x, rp.u, rq.u, rr.u);
+      tet_a_forces(pg, rp.x, ra.x, rp.u, ra.u, lam6, mu6, fa, fr, fq);
     }
   }
   if (ABLATE == 8) {
@@ -234,8 +259,7 @@ __device__ __forceinline__ void item_forces(const uint2 w, const double *rec, do
     } else {
       // B as (p; b, q, r)
       Vec3 gq, gr;
-      tet_forces(rp.x, rb.x, rq.x, rr.x, rp.u, rb.u, rq.u, rr.u, lam, mu, fb, gq, gr);
-      fp = add3(fp, neg_sum3(fb, gq, gr));
+      tet_b_forces(pg, rp.x, rb.x, rp.u, rb.u, lam6, mu6, fb, gq, gr);
       fq = add3(fq, gq);
       fr = add3(fr, gr);
     }
@@ -246,6 +270,8 @@ __device__ __forceinline__ void item_forces(const uint2 w, const double *rec, do
     if (ABLATE != 1) flush<ALL_OWNED>(acc, it.b, n_owned, fb);
     else sink += fb.x + fb.y + fb.z;
   }
+  // the forces of an element sum to zero, those of the pair too: p gets minus the sum of the other four (fb = 0 without B)
+  if (ABLATE != 7) fp = neg_sum3(add3(fa, fb), fq, fr);
   if (ABLATE == 1) {
     sink += fp.x + fp.y + fp.z + fq.x + fq.y + fq.z + fr.x + fr.y + fr.z;
     return;
@@ -422,7 +448,7 @@ __global__ void __launch_bounds__(SAA_LB) fused_step_kernel(DeviceMesh m, const 
 #pragma unroll
     for (int j = 0; j < kPreConn; ++j)
       if (tid + j * nt < bd.n_interior)
-        item_forces<ABLATE, NoHook, true>(cpre[j], rec, acc, bd.n_owned, m.lambda_, m.mu, tid, sink, T);
+        item_forces<ABLATE, NoHook, true>(cpre[j], rec, acc, bd.n_owned, m.lambda6, m.mu6, tid, sink, T);
     // (rare) further interior sweeps, software-pipelined: the next connectivity entry is in flight while
     // the current element computes - a dependent global load per sweep would expose its L2 latency
     if (tid + kPreConn * nt < bd.n_interior) {
@@ -430,7 +456,7 @@ __global__ void __launch_bounds__(SAA_LB) fused_step_kernel(DeviceMesh m, const 
       uint2 cur = conn[tid + kPreConn * nt];
       for (int e = tid + kPreConn * nt; e < bd.n_interior; e += nt) {
         const uint2 nxt = conn[min(e + nt, last)];
-        item_forces<ABLATE, NoHook, true>(cur, rec, acc, bd.n_owned, m.lambda_, m.mu, tid, sink, T);
+        item_forces<ABLATE, NoHook, true>(cur, rec, acc, bd.n_owned, m.lambda6, m.mu6, tid, sink, T);
         cur = nxt;
       }
     }
@@ -492,7 +518,7 @@ __global__ void __launch_bounds__(SAA_LB) fused_step_kernel(DeviceMesh m, const 
     const int last = bd.n_elem - 1;
     for (int e = e_b0; e < bd.n_elem; e += nt) {
       const uint2 nxt = conn[min(e + nt, last)];
-      item_forces<ABLATE>(bcur, rec, acc, bd.n_owned, m.lambda_, m.mu, tid, sink, T);
+      item_forces<ABLATE>(bcur, rec, acc, bd.n_owned, m.lambda6, m.mu6, tid, sink, T);
       bcur = nxt;
     }
   }
@@ -791,7 +817,7 @@ __global__ void __launch_bounds__(SAA_LB) persistent_steps_kernel(DeviceMesh m, 
     };
     // (interior items: the variant of the item code without ownership tests)
     if (tid < n_pre)
-      item_forces<0, decltype(fetch), true>(connl[tid], rec, acc, bd.n_owned, m.lambda_, m.mu, tid, sink, nullptr, fetch);
+      item_forces<0, decltype(fetch), true>(connl[tid], rec, acc, bd.n_owned, m.lambda6, m.mu6, tid, sink, nullptr, fetch);
     else
       fetch();
     PSTAMP(0)
@@ -839,10 +865,11 @@ __global__ void __launch_bounds__(SAA_LB) persistent_steps_kernel(DeviceMesh m, 
     //         The boundary part starts on a wave boundary (the interior part is padded to a multiple of 64 slots):
     //         the plan packed each list for the LDS banks from ITS first item, in groups of 16 / 32 lanes.
     //         (the ownership-test-free variant of the interior items, which the first round and the fused kernel use,
-    //         was measured here too, behind a wave-uniform branch: 8.60-8.67 against 8.43 us/step)
+    //         was measured here too, behind a wave-uniform branch: 8.60-8.67 against 8.43 us/step in round 2, 8.06 against
+    //         8.03 in round 3 with 104 instead of 112 registers in use)
     for (int p = tid; p < n_post; p += nt) {
       const int e = p < n_ir_pad ? (p < n_ir ? n_pre + p : -1) : bd.n_interior + (p - n_ir_pad);
-      if (e >= 0) item_forces<0>(connl[e], rec, acc, bd.n_owned, m.lambda_, m.mu, tid, sink);
+      if (e >= 0) item_forces<0>(connl[e], rec, acc, bd.n_owned, m.lambda6, m.mu6, tid, sink);
     }
     PSTAMP(4)
     // ---- 5. update of the owned dofs: LDS operands; the new value leaves as a plain double (state) and as a
@@ -1025,16 +1052,16 @@ __global__ void __launch_bounds__(SAA_LB) det_items_kernel(DeviceMesh m, const d
     // exactly the evaluation order of item_forces: A as (p; a, r, q), B as (p; b, q, r), face forces summed in registers
     const Rec rp = load_rec(rec, it.p), rq = load_rec(rec, it.q), rr = load_rec(rec, it.r), ra = load_rec(rec, it.a);
     Vec3 fa, fp, fq, fr, fb = {0, 0, 0};
-    tet_forces(rp.x, ra.x, rr.x, rq.x, rp.u, ra.u, rr.u, rq.u, m.lambda_, m.mu, fa, fr, fq);
-    fp = neg_sum3(fa, fr, fq);
+    const PairShared pg = pair_shared(rp.x, rq.x, rr.x, rp.u, rq.u, rr.u);
+    tet_a_forces(pg, rp.x, ra.x, rp.u, ra.u, m.lambda6, m.mu6, fa, fr, fq);
     if (it.pair) {
       const Rec rb = load_rec(rec, it.b);
       Vec3 gq, gr;
-      tet_forces(rp.x, rb.x, rq.x, rr.x, rp.u, rb.u, rq.u, rr.u, m.lambda_, m.mu, fb, gq, gr);
-      fp = add3(fp, neg_sum3(fb, gq, gr));
+      tet_b_forces(pg, rp.x, rb.x, rp.u, rb.u, m.lambda6, m.mu6, fb, gq, gr);
       fq = add3(fq, gq);
       fr = add3(fr, gr);
     }
+    fp = neg_sum3(add3(fa, fb), fq, fr);
     double *o = item_force + 15 * (int64_t)(bd.elem_off + e);
     o[0] = fa.x; o[1] = fa.y; o[2] = fa.z; o[3] = fp.x; o[4] = fp.y; o[5] = fp.z; o[6] = fq.x; o[7] = fq.y; o[8] = fq.z;
     o[9] = fr.x; o[10] = fr.y; o[11] = fr.z; o[12] = fb.x; o[13] = fb.y; o[14] = fb.z;

@@ -867,6 +867,8 @@ bool build_once(int32_t n_nodes, int32_t n_elems, const double *xyz, const int32
   std::vector<std::vector<uint16_t>> block_halo_perm(n_blocks);  // non-empty: old -> new position in the block's halo list
   const char *shp_env = getenv("SAA_PLAN_SHAPE_PAIRS");
   const bool shape_pairs = !(shp_env && shp_env[0] == '0');
+  const char *force_env = getenv("SAA_PLAN_FORCE_TRIALS");  // (experiments: try the other numberings on every block)
+  const bool force_trials = force_env && force_env[0] == '1';
   const char *lat_env = getenv("SAA_PLAN_LATTICE_ORDERS");
   const bool lattice_orders = !(lat_env && lat_env[0] == '0');
   std::atomic<int32_t> renumbered{0};
@@ -929,53 +931,66 @@ bool build_once(int32_t n_nodes, int32_t n_elems, const double *xyz, const int32
         std::copy(&items[8 * static_cast<size_t>(i)], &items[8 * static_cast<size_t>(i)] + 8,
                   &out[8 * static_cast<size_t>(dst)]);
       }
-      PackStats st_in;
-      int32_t m_in = reorder_for_lds(out.data(), n_in, d.n_owned, pad, part_a, st_in);
-      // Which axis runs fastest inside the block decides how well its interior items pack: with L layers along the
-      // (outer, middle, inner) axes the lattice index is inner + L_in * (middle + L_mid * outer), and the translates of an
-      // element pair reach all 32 bank residues only if those strides are not all multiples of 8 - a 12 x 8 x 8-node box
-      // numbered (x, y, z) packs a quarter of its interior items clash-free, numbered (y, z, x) three quarters; ragged
-      // layers at the block faces decide the rest.  So: when the plan order does badly, the other five lexicographic
-      // orders of the owned nodes are tried on the interior items and the best one becomes the block's numbering.
-      if (alt_axes && n_in >= 256 && 10 * st_in.by_construction < 6 * n_in) {
-        int best_q = 0;
-        int64_t best_constr = st_in.by_construction;
-        std::vector<uint16_t> best_pi;
-        // (orders 6..11: pseudo-lattice numberings, block_lattice_order)
-        for (int q = 1; q < (lattice_orders && h_mesh > 0.0 ? 12 : 6); ++q) {
-          if (q < 6)
-            block_axis_order(xyz, plan.new_to_old.data() + d.node_start, d.n_owned, q, pi);
-          else
-            block_lattice_order(xyz, plan.new_to_old.data() + d.node_start, d.n_owned, h_mesh, q - 6, pi);
-          trial.assign(out.begin(), out.begin() + 8 * static_cast<size_t>(n_in));
-          relabel_owned(trial.data(), n_in, d.n_owned, pi);
-          PackStats st_q;
-          (void)reorder_for_lds(trial.data(), n_in, d.n_owned, pad, part_q, st_q);
-          if (st_q.by_construction > best_constr + n_in / 10) {
-            best_constr = st_q.by_construction;
-            best_q = q;
-            best_pi = pi;
+      // One numbering of the block's nodes, packed: q = 0 the plan order (lexicographic by exact coordinates, x fastest),
+      // 1..5 the other lexicographic orders of the owned nodes, 6..11 pseudo-lattice numberings of owned AND halo nodes
+      // (block_lattice_order).  cost = extra LDS passes, weighted as in reorder_for_lds (12 per read level, 21 per atomic).
+      struct Trial {
+        std::vector<uint16_t> pa, pb, pio, pih;
+        PackStats si, sb;
+        int32_t mi = 0, mb = 0;
+        double cost = 0.0;
+      };
+      auto evaluate = [&](int q, Trial &tr) {
+        trial.assign(out.begin(), out.end());
+        tr.pio.clear();
+        tr.pih.clear();
+        if (q >= 1 && q < 6) block_axis_order(xyz, plan.new_to_old.data() + d.node_start, d.n_owned, q, tr.pio);
+        if (q >= 6) {
+          block_lattice_order(xyz, plan.new_to_old.data() + d.node_start, d.n_owned, h_mesh, q - 6, tr.pio);
+          if (d.n_halo > 0) {  // halo list in the same pseudo-lattice: the boundary items form classes too
+            const LatticeColours lc = lattice_colours(xyz, plan.new_to_old.data() + d.node_start, d.n_owned, h_mesh, q - 6);
+            std::vector<int> colour(d.n_halo);
+            for (int32_t hh = 0; hh < d.n_halo; ++hh)
+              colour[hh] = lc(xyz + 3 * static_cast<int64_t>(plan.new_to_old[plan.halo_ids[d.halo_off + hh]]));
+            assign_by_colour(colour, d.n_owned, tr.pih);
+            relabel_halo(trial.data() + 8 * static_cast<size_t>(n_in), ni - n_in, d.n_owned, tr.pih);
           }
         }
-        if (best_q != 0) {
-          relabel_owned(out.data(), ni, d.n_owned, best_pi);
-          st_in = PackStats();
-          m_in = reorder_for_lds(out.data(), n_in, d.n_owned, pad, part_a, st_in);
-          block_perm[b] = best_pi;
-        }
-        if (best_q >= 6 && d.n_halo > 0) {  // halo list in the same pseudo-lattice: the boundary items form classes too
-          const LatticeColours lc = lattice_colours(xyz, plan.new_to_old.data() + d.node_start, d.n_owned, h_mesh, best_q - 6);
-          std::vector<int> colour(d.n_halo);
-          for (int32_t hh = 0; hh < d.n_halo; ++hh)
-            colour[hh] = lc(xyz + 3 * static_cast<int64_t>(plan.new_to_old[plan.halo_ids[d.halo_off + hh]]));
-          assign_by_colour(colour, d.n_owned, block_halo_perm[b]);
-          relabel_halo(out.data() + 8 * static_cast<size_t>(n_in), ni - n_in, d.n_owned, block_halo_perm[b]);
-          ++renumbered;
+        if (!tr.pio.empty()) relabel_owned(trial.data(), ni, d.n_owned, tr.pio);
+        tr.si = PackStats();
+        tr.sb = PackStats();
+        tr.mi = reorder_for_lds(trial.data(), n_in, d.n_owned, pad, tr.pa, tr.si);
+        tr.mb = reorder_for_lds(trial.data() + 8 * static_cast<size_t>(n_in), ni - n_in, d.n_owned, pad, tr.pb, tr.sb);
+        tr.cost = 12.0 * (tr.si.read_mult + tr.sb.read_mult - tr.si.read_cnt - tr.sb.read_cnt) +
+                  21.0 * (tr.si.atomic_mult + tr.sb.atomic_mult - tr.si.atomic_cnt - tr.sb.atomic_cnt);
+      };
+      // Which axis runs fastest inside the block decides how well its items pack: with L layers along the (outer, middle,
+      // inner) axes the lattice index is inner + L_in * (middle + L_mid * outer), and the translates of an element pair
+      // reach all 32 bank residues only if those strides are not all multiples of 8 - a 12 x 8 x 8-node box numbered
+      // (x, y, z) packs a quarter of its interior items clash-free, numbered (y, z, x) three quarters; ragged layers at the
+      // block faces and the residues of the halo slots decide the rest.  So every numbering is tried where the plan order
+      // leaves something to gain, and the cheapest becomes the block's (it has to beat the plan order by 3 %).
+      Trial best, cand;
+      evaluate(0, best);
+      int best_q = 0;
+      const int64_t constr0 = best.si.by_construction + best.sb.by_construction;
+      if (alt_axes && ni >= 256 && (force_trials || 10 * constr0 < 7 * static_cast<int64_t>(best.mi + best.mb))) {
+        const double cost0 = best.cost;
+        for (int q = 1; q < (lattice_orders && h_mesh > 0.0 ? 12 : 6); ++q) {
+          evaluate(q, cand);
+          if (cand.cost < 0.97 * cost0 && cand.cost < best.cost) {
+            std::swap(best, cand);
+            best_q = q;
+          }
         }
       }
-      PackStats st_bd;
-      const int32_t m_bd = reorder_for_lds(out.data() + 8 * static_cast<size_t>(n_in), ni - n_in, d.n_owned, pad,
-                                           part_b, st_bd);
+      if (!best.pio.empty()) block_perm[b] = best.pio;
+      if (!best.pih.empty()) block_halo_perm[b] = best.pih;
+      renumbered += best_q >= 6;
+      part_a.swap(best.pa);
+      part_b.swap(best.pb);
+      const PackStats st_in = best.si, st_bd = best.sb;
+      const int32_t m_in = best.mi, m_bd = best.mb;
       stats[t].add(st_in);
       stats[t].add(st_bd);
       out = part_a;
