@@ -46,30 +46,69 @@ def local_mat_node(G_ID, L_N):
     return order[pos].tolist()
 
 
+_MULTI_HOLDER_CACHE = {}
+
+
+def _multi_holder_dofs(size, rank, L_g, Local_nodes, device, group):
+    """Global dofs of the nodes held by THREE or more ranks (one collective, cached per node list): the only places where
+    the order of a sum over the ranks matters (a + b == b + a, but (a + b) + c is not a + (b + c))."""
+    import torch
+    import torch.distributed as dist
+
+    nodes = np.asarray(Local_nodes, dtype=np.int64)
+    key = (size, rank, int(L_g), str(device), nodes.tobytes())
+    hit = _MULTI_HOLDER_CACHE.get(key)
+    if hit is None:
+        cnt = torch.zeros(int(L_g), dtype=torch.int32, device=device)
+        cnt[torch.as_tensor(nodes, device=device)] = 1
+        dist.all_reduce(cnt, group=group)
+        multi = torch.nonzero(cnt >= 3).reshape(-1)
+        hit = (3 * multi[:, None] + torch.arange(3, device=device)[None, :]).reshape(-1)
+        if len(_MULTI_HOLDER_CACHE) > 16:
+            _MULTI_HOLDER_CACHE.clear()
+        _MULTI_HOLDER_CACHE[key] = hit
+    return hit
+
+
 def syn_cpus(size, rank, f, L_g, Local_nodes, group=None):
     """Sum of every rank's local force vector on the global numbering, restricted back
     (``Distributed_tools.py:77-92``).  One ``all_reduce`` instead of gather + root add + bcast; must be
-    entered by every rank, like the reference's.  ``f`` may be NumPy ``(3n,1)`` (returns NumPy) or a torch
-    tensor on the process group's device (returns a tensor)."""
+    entered by every rank, like the reference's.  The reference's root adds the ranks' vectors in RANK order
+    (``:84-86``); an all-reduce adds them in whatever order its ring takes, which gives other last bits wherever three
+    or more ranks hold a node - those dofs (none on slab partitions; edges and corners of a k-way partition) are gathered
+    and summed again in rank order, so that the result has the reference's bits on every rank.  ``f`` may be NumPy
+    ``(3n,1)`` (returns NumPy) or a torch tensor on the process group's device (returns a tensor)."""
     import torch
     import torch.distributed as dist
 
     dof = node_to_dof(3, [0, 1, 2], Local_nodes)
+
+    def reduce_in_rank_order(g):
+        local = g.clone()
+        dist.all_reduce(g, group=group)
+        multi = _multi_holder_dofs(size, rank, L_g, Local_nodes, g.device, group)
+        if multi.numel() > 0:
+            parts = [torch.empty((multi.numel(), 1), dtype=g.dtype, device=g.device) for _ in range(size)]
+            dist.all_gather(parts, local[multi].contiguous(), group=group)
+            acc = torch.zeros_like(parts[0])
+            for p in parts:  # f_global[...] += f of rank 0, 1, 2, ... (ranks without the node add an exact zero)
+                acc = acc + p
+            g[multi] = acc
+        return g
+
     if isinstance(f, torch.Tensor):
         g = torch.zeros((3 * L_g, 1), dtype=f.dtype, device=f.device)
         idx = torch.as_tensor(dof, device=f.device)
         g[idx] = f.reshape(-1, 1)
         if size != 1:
-            dist.all_reduce(g, group=group)
+            g = reduce_in_rank_order(g)
         return g[idx]
     g = torch.zeros((3 * L_g, 1), dtype=torch.float64)
     g[dof] = torch.from_numpy(np.ascontiguousarray(f, dtype=np.float64).reshape(-1, 1))
     if size != 1:
         backend = dist.get_backend(group)
         if backend == "nccl":
-            gd = g.cuda()
-            dist.all_reduce(gd, group=group)
-            g = gd.cpu()
+            g = reduce_in_rank_order(g.cuda()).cpu()
         else:
-            dist.all_reduce(g, group=group)
+            g = reduce_in_rank_order(g)
     return g.numpy()[dof]

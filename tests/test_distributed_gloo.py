@@ -194,3 +194,44 @@ def test_multi_process_cpu_baseline_equals_the_oracle_step():
         # same per-step operations in the same order; the lumped mass comes from the closed form instead of the
         # oracle's element loop (1e-16 apart), hence not bit-identical
         assert np.linalg.norm(out["states"][r] - d0s[r]) < 1e-13 * np.linalg.norm(d0s[r])
+
+
+def _syn_cpus_worker(rank, world, port, out_dir):
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from synchronization_avoiding_algorithms_amd.Tools.Distributed_tools import syn_cpus
+
+    g = np.load(os.path.join(out_dir, "case.npz"))
+    nodes, f = g[f"nodes{rank}"], g[f"f{rank}"]
+    out = syn_cpus(world, rank, f, int(g["L_g"]), nodes.tolist())
+    again = syn_cpus(world, rank, torch.from_numpy(f), int(g["L_g"]), nodes.tolist())  # tensor in, tensor out; cached lists
+    np.savez(os.path.join(out_dir, f"syn{rank}.npz"), out=out, again=again.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_dropin_syn_cpus_sums_in_rank_order_where_three_ranks_meet(tmp_path):
+    """``syn_cpus`` adds the ranks' vectors in rank order on the root (Distributed_tools.py:84-86).  With values chosen so
+    that the order of a three-term sum shows in the last bits, the drop-in must return exactly those bits on every rank -
+    also for nodes held by all four ranks - not whatever order an all-reduce happens to take."""
+    from oracle import fem_oracle as fo
+
+    world, L_g = 4, 40
+    rng = np.random.default_rng(5)
+    lists = [np.sort(rng.choice(L_g, size=22, replace=False)) for _ in range(world)]
+    lists[0][:3] = lists[1][:3] = lists[2][:3] = lists[3][:3] = [1, 2, 3]  # held by all four
+    lists = [np.unique(x) for x in lists]
+    forces = [rng.uniform(-1, 1, size=(3 * len(x), 1)) * 10.0 ** rng.integers(-8, 8, size=(3 * len(x), 1)) for x in lists]
+    np.savez(tmp_path / "case.npz", L_g=L_g, **{f"nodes{r}": lists[r] for r in range(world)},
+             **{f"f{r}": forces[r] for r in range(world)})
+    want = fo.syn_sum(forces, lists, L_g)
+    holders = np.zeros(L_g, dtype=int)
+    for x in lists:
+        holders[x] += 1
+    assert (holders >= 3).sum() >= 5
+    port = free_port()
+    mp.spawn(_syn_cpus_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        got = np.load(tmp_path / f"syn{r}.npz")
+        assert np.array_equal(got["out"], want[r]) and np.array_equal(got["again"], want[r]), r

@@ -8,7 +8,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 SA_EPOCHS = 60
-SA_ERR_BOUNDS = (0.5, 0.5, 0.5)  # per predicted window, see test_two_ranks_launch_themselves_and_print_one_line
+SA_ERR_BOUNDS = (0.075, 0.07, 0.11)  # per predicted window: 3x profiles/r03_sa_fixed_epochs.txt (0.0246, 0.0225, 0.0370)
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
