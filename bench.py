@@ -820,19 +820,32 @@ def main():
             k_r, w_r = min(args.steps, 2000), min(args.warmup, 200)
             args_steps, args_warmup = args.steps, args.warmup
             args.steps, args.warmup = k_r, w_r
-            try:
-                part_r, elapsed_r, ok_r = build_and_time("rccl" if args.backend == "nccl" else "torch")
-                how = part_r.exchange
-                part_r.close()
-            except Exception as e:  # noqa: BLE001 - reported, never fatal for the headline line
-                ok_r, how, elapsed_r = False, f"failed: {e}"[:200], float("nan")
+            # twice: eager launches first (fused kernel, ncclAllReduce, finish kernel enqueued one by one - the route that
+            # has run before), then the same steps as replayed HIP graphs of three steps each (saa_step_synced's default);
+            # the first figure is in the line before the second route is tried
+            res, ok_any = {}, False
+            for route, env in (("eager", "0"), ("graph", "1")):
+                os.environ["SAA_SYNCED_GRAPH"] = env
+                try:
+                    part_r, elapsed_r, ok_r = build_and_time("rccl" if args.backend == "nccl" else "torch")
+                    how = part_r.exchange
+                    part_r.close()
+                except Exception as e:  # noqa: BLE001 - reported, never fatal for the headline line
+                    ok_r, how, elapsed_r = False, f"failed: {e}"[:200], float("nan")
+                res[route] = ({"value": ne_total * k_r / elapsed_r, "ms_per_step": 1e3 * elapsed_r / k_r, "exchange": how}
+                              if ok_r else {"value": None, "exchange": how})
+                ok_any = ok_any or ok_r
+                best = max((r for r in res.values() if r["value"]), key=lambda r: r["value"], default=None)
+                put("rccl_allreduce", dict(best or {"value": None, "exchange": how}, unit="element-updates/s", steps=k_r,
+                                           warmup=w_r, routes=dict(res),
+                                           note="same partitions; shared-node forces summed by an all-reduce of "
+                                                f"{3 * len(gshared)} doubles every step instead of the peer exchange; "
+                                                "value = the faster of the two launch routes"))
+                if how != "rccl":  # (the torch transport has no graph route)
+                    break
+            os.environ.pop("SAA_SYNCED_GRAPH", None)
             args.steps, args.warmup = args_steps, args_warmup
-            put("rccl_allreduce", ({"value": ne_total * k_r / elapsed_r, "unit": "element-updates/s",
-                                    "ms_per_step": 1e3 * elapsed_r / k_r, "steps": k_r, "warmup": w_r, "exchange": how,
-                                    "note": "same partitions; shared-node forces summed by an all-reduce of "
-                                            f"{3 * len(gshared)} doubles every step instead of the peer exchange"}
-                                   if ok_r else {"value": None, "exchange": how}))
-            legs.end("rccl_allreduce", "done" if ok_r else "failed")
+            legs.end("rccl_allreduce", "done" if ok_any else "failed")
     legs.emit(final=True)
     if world > 1:
         dist.barrier()

@@ -641,6 +641,21 @@ __global__ void peer_selftest_kernel(PeerMap pm, const double *__restrict__ own,
 // (an acquire in a polling loop would invalidate the XCD's L2 on every iteration).
 
 // (doubles) d^(n-1) of the owned dofs follows the node records and the [max_owned][3] force accumulators
+// n_words 4-byte words of a contiguous global array straight into LDS by LDS-DMA (global_load_lds_dword: the data never
+// passes through registers and nothing waits for it until the next vmcnt(0) - the workgroup barrier behind the image
+// staging).  The hardware writes lane l of a wave-instruction to (wave-uniform LDS base) + 4*l, so every wave copies whole
+// 64-word chunks; 4-byte granules because neither side is aligned better than that for every block.
+typedef __attribute__((address_space(1))) const uint32_t *GlobalWords;
+typedef __attribute__((address_space(3))) uint32_t *LdsWords;
+__device__ __forceinline__ void dma_words(const void *src, void *dst_lds, int n_words, int tid, int nt) {
+  GlobalWords s = (GlobalWords)src;
+  LdsWords d = (LdsWords)dst_lds;
+  for (int w0 = tid & ~63; w0 < n_words; w0 += nt) {  // w0: first word of this wave's chunk (wave-uniform)
+    const int i = w0 + (tid & 63);
+    if (i < n_words) __builtin_amdgcn_global_load_lds(s + i, d + w0, 4, 0, 0);
+  }
+}
+
 __host__ __device__ inline int persist_off_dn(int max_local, int max_owned) { return 6 * max_local + 3 * max_owned; }
 
 #ifndef SAA_PERSIST_PRE
@@ -729,27 +744,75 @@ __global__ void __launch_bounds__(SAA_LB) persistent_steps_kernel(DeviceMesh m, 
   }
 
   // ---- once: the block's image (halo displacements of the first step included) -----------------------
-  for (int i = tid; i < n_own3; i += nt) {
-    const int n = i / 3, c = i - 3 * n;
-    rec[6 * n + c] = m.xyz[base + i];
-    rec[6 * n + 3 + c] = a.g0[base + i];
-    dnl[i] = a.g1[base + i];
-    acc[3 * n + c] = 0.0;
-  }
-  for (int n = tid; n < bd.n_owned; n += nt) {
-    massl[n] = m.mass_node[bd.node_start + n];
-    fextl[n] = m.fext_yz[bd.node_start + n];
-    tagl[n] = m.tag[bd.node_start + n];
-  }
-  for (int i = tid; i < n_halo3; i += nt) {
-    const int n = i / 3, c = i - 3 * n;
-    const int64_t g = 3 * (int64_t)hid[n] + c;
-    rec[6 * (bd.n_owned + n) + c] = m.xyz[g];
-    rec[6 * (bd.n_owned + n) + 3 + c] = a.g0[g];
-    hgl[i] = (int32_t)g;
+  //      A launch of 20 steps pays this staging with 4 % of its time, so every request leaves before the first answer is
+  //      used: what is a plain copy of a contiguous array - d^(n-1), nodal mass and load, tags, work items: half of the
+  //      image - goes global -> LDS by LDS-DMA (no registers, nothing to wait for until the barrier below), the node
+  //      records, which interleave coordinates and displacements, through registers, all sweeps requested before the
+  //      first is stored (in loops that load and store per sweep the requests of one sweep only left when the previous
+  //      sweep's data had arrived: eight memory round trips in a row at the start of every launch).
+  {
+    constexpr int kOwnSweeps = 3, kHaloSweeps = 2;
+    int64_t hgi[kHaloSweeps];
+    int32_t hnode[kHaloSweeps];
+    double ox[kOwnSweeps], ou[kOwnSweeps], hx[kHaloSweeps], hu[kHaloSweeps];
+    // (the halo ids first: the only requests something else depends on - while an LDS-DMA is in flight the compiler
+    // waits for ALL outstanding memory operations at the first use of a loaded value, so they travel with everything else)
+    // (all of them unconditional, with clamped indices - the plan pads its lists by one entry: a load under a branch is
+    // waited for where the branch ends)
+#pragma unroll
+    for (int j = 0; j < kHaloSweeps; ++j) hnode[j] = hid[min(tid + j * nt, max(n_halo3 - 1, 0)) / 3];
+    dma_words(a.g1 + base, dnl, 2 * n_own3, tid, nt);
+    dma_words(m.mass_node + bd.node_start, massl, 2 * bd.n_owned, tid, nt);
+    dma_words(m.fext_yz + bd.node_start, fextl, 2 * bd.n_owned, tid, nt);
+    dma_words(m.tag + bd.node_start, tagl, bd.n_owned, tid, nt);
+    dma_words(m.conn + bd.elem_off, connl, 2 * bd.n_elem, tid, nt);
+#pragma unroll
+    for (int j = 0; j < kOwnSweeps; ++j) {
+      const int i = min(tid + j * nt, n_own3 - 1);
+      ox[j] = m.xyz[base + i];
+      ou[j] = a.g0[base + i];
+    }
+#pragma unroll
+    for (int j = 0; j < kHaloSweeps; ++j) {
+      hgi[j] = 3 * (int64_t)hnode[j] + (min(tid + j * nt, max(n_halo3 - 1, 0)) % 3);
+      hx[j] = m.xyz[hgi[j]];
+      hu[j] = a.g0[hgi[j]];
+    }
+#pragma unroll
+    for (int j = 0; j < kOwnSweeps; ++j) {
+      const int i = tid + j * nt;
+      if (i < n_own3) {
+        const int n = i / 3, c = i - 3 * n;
+        rec[6 * n + c] = ox[j];
+        rec[6 * n + 3 + c] = ou[j];
+        acc[i] = 0.0;
+      }
+    }
+    for (int i = tid + kOwnSweeps * nt; i < n_own3; i += nt) {  // (blocks larger than the depth above)
+      const int n = i / 3, c = i - 3 * n;
+      rec[6 * n + c] = m.xyz[base + i];
+      rec[6 * n + 3 + c] = a.g0[base + i];
+      acc[i] = 0.0;
+    }
+#pragma unroll
+    for (int j = 0; j < kHaloSweeps; ++j) {
+      const int i = tid + j * nt;
+      if (i < n_halo3) {
+        const int n = i / 3, c = i - 3 * n;
+        rec[6 * (bd.n_owned + n) + c] = hx[j];
+        rec[6 * (bd.n_owned + n) + 3 + c] = hu[j];
+        hgl[i] = (int32_t)hgi[j];
+      }
+    }
+    for (int i = tid + kHaloSweeps * nt; i < n_halo3; i += nt) {
+      const int n = i / 3, c = i - 3 * n;
+      const int64_t g = 3 * (int64_t)hid[n] + c;
+      rec[6 * (bd.n_owned + n) + c] = m.xyz[g];
+      rec[6 * (bd.n_owned + n) + 3 + c] = a.g0[g];
+      hgl[i] = (int32_t)g;
+    }
   }
   if (tid == 0 && n_halo3 == 0) hgl[0] = 0;  // the clamped prefetch below reads index 0 even without a halo
-  for (int e = tid; e < bd.n_elem; e += nt) connl[e] = m.conn[bd.elem_off + e];
   if (PEER) {
     // the block's push / receive records (static; one pair per shared node it owns) behind the image: the shared nodes
     // are a serial tail of a face block's step, and two dependent global loads less in it shorten every block's step

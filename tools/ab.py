@@ -4,7 +4,8 @@ process order, alternating, so that clocks and box are the same for all of them.
 
     python tools/ab.py name=path/to/lib.so [name=...] [--cases=resident19,fused19,fused38] [--rounds=3]
 
-Cases: resident<n> (saa_step through the resident kernel, 1000-step launches), fused<n> (one launch per step).
+Cases: resident<n> (saa_step through the resident kernel, 1000-step launches), resident20x<n> (the same in calls of 20
+steps, wall clock), fused<n> (one launch per step).
 Each (library, case) runs in a child process (a library is loaded once per process); prints us/step per round and the
 median."""
 import json
@@ -21,16 +22,28 @@ sys.argv = ['bench.py']
 import numpy as np
 from bench import build_rank_solver, bench_mesh
 case, kind = sys.argv_case
-n = int(''.join(ch for ch in case if ch.isdigit()))
+n = int(''.join(ch for ch in case.split('x')[-1] if ch.isdigit()))
 mesh = bench_mesh(n, kind)
 sol, lay, _, _ = build_rank_solver(mesh, 1, 0, 0)
 resident = case.startswith('resident')
 if not resident:
     sol.set_resident_kernel(False)
 assert sol.resident_kernel_info()['capable'] == resident, sol.resident_kernel_info()
-steps = 4000 if resident else (1000 if n < 30 else 300)
-sol.time_steps(steps)
-out = [1e3 * sol.time_steps(steps) / steps for _ in range(3)]
+import time
+if case.startswith('resident20x'):  # calls of 20 steps (the driver's --steps 20): one resident launch per call, wall clock
+    def run():
+        sol.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(400):
+            sol.step(20)
+        sol.synchronize()
+        return 1e6 * (time.perf_counter() - t0) / 8000
+    run()
+    out = [run() for _ in range(3)]
+else:
+    steps = 4000 if resident else (1000 if n < 30 else 300)
+    sol.time_steps(steps)
+    out = [1e3 * sol.time_steps(steps) / steps for _ in range(3)]
 d0 = sol.get_state()[0]
 print(json.dumps({'us': out, 'norm': float(np.linalg.norm(d0)), 'plan': sol.plan_stats()}))
 """
