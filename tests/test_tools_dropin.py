@@ -104,12 +104,24 @@ def test_shape_functions_and_quadrature_match_the_reference():
             assert np.abs(S.Jacobian(1, P, x) - g["J"][e, q]).max() < 1e-15
             assert S.IsoparametricMap(1, P, x).shape == (3, 1)
             assert np.abs(S.IsoparametricMap(1, P, x) - g["X"][e, q]).max() < 4e-15
+    # p = 2 (10-node tets with curved edges) and the 14-point rule: not on the dynamic path, part of the Tools surface
+    g2 = load_golden("shape_quadrature_p2.npz")
+    nodes, weights = Q.Gauss_Legendre(4)
+    assert np.array_equal(nodes, g2["q4_nodes"]) and np.array_equal(weights, g2["q4_weights"])
+    assert abs(weights.sum() - 1.0 / 6) < 1e-15
+    assert np.abs(np.array([S.Shape_Function(2, x) for x in g2["xi"]]) - g2["N"]).max() < 1e-15
+    assert np.abs(np.array([S.Shape_Deri(2, x) for x in g2["xi"]]) - g2["dN"]).max() < 1e-15
+    assert np.abs(np.array([S.Shape_Function(2, x) for x in g2["xi"]]).sum(axis=1) - 1.0).max() < 1e-15  # partition of unity
+    for e, P in enumerate(g2["P"]):
+        for q, x in enumerate(g2["xi"]):
+            assert np.abs(S.Jacobian(2, P, x) - g2["J"][e, q]).max() < 1e-14
+            assert np.abs(S.IsoparametricMap(2, P, x) - g2["X"][e, q]).max() < 1e-14
     import pytest
 
     with pytest.raises(NotImplementedError):
-        S.Shape_Function(2, [0.1, 0.1, 0.1])
+        S.Shape_Function(3, [0.1, 0.1, 0.1])
     with pytest.raises(NotImplementedError):
-        Q.Gauss_Legendre(4)
+        Q.Gauss_Legendre(5)
 
 
 def test_every_tools_name_the_reference_drivers_use_exists():
