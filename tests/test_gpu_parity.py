@@ -85,8 +85,9 @@ def test_serial_trajectory_against_reference(beam_coarse):
 @pytest.mark.parametrize("n,block_nodes,threads", [(3, 0, 0), (4, 64, 128), (6, 200, 256), (6, 0, 1024), (7, 500, 512)])
 def test_synthetic_beam_against_oracle(n, block_nodes, threads, monkeypatch, capfd):
     """Multi-block plans (halo nodes, duplicated border elements) on the synthetic cantilever.  The last case has
-    8 x 8-node block cross-sections: every block renumbers its nodes with another axis running fastest (saa_plan.cpp:
-    block_axis_order), which moves the global numbering and the halo lists of its neighbours along."""
+    8 x 8-node block cross-sections, which pack badly in the plan order: most blocks renumber their nodes (saa_plan.cpp:
+    block_lattice_order, with the halo lists re-ordered to match; block_axis_order with SAA_PLAN_LATTICE_ORDERS=0), which
+    moves the global numbering and the halo lists of their neighbours along."""
     fo = _oracle()
     from synchronization_avoiding_algorithms_amd.mesh import structured_beam
 
@@ -96,7 +97,10 @@ def test_synthetic_beam_against_oracle(n, block_nodes, threads, monkeypatch, cap
     monkeypatch.delenv("SAA_PLAN_DEBUG")
     log = capfd.readouterr().err
     if n == 7:
-        assert "23 of 23 blocks took another axis order" in log, log[-2000:]
+        import re
+
+        took = re.search(r"plan: (\d+) of 23 blocks took another axis order", log)
+        assert took and int(took.group(1)) >= 10, log[-2000:]
     st = sol.plan_stats()
     if block_nodes:
         assert st["n_blocks"] > 1 and st["n_halo_total"] > 0
