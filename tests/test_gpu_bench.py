@@ -85,3 +85,14 @@ def test_headline_at_the_drivers_flags_is_warm():
     kernel_rate = 1028850 / (roof["us_per_step"] * 1e-6)
     assert out["value"] > kernel_rate / 1.5, (out["value"], kernel_rate)
     assert out["timed_calls"] * out["steps"] * out["ms_per_step"] >= 45.0  # the timed region lasted >= ~50 ms
+
+
+def test_a_short_budget_takes_the_small_cpu_sample_and_says_so():
+    """With little of the budget left the CPU baseline falls back from the 1M-tet mesh (25 s of assembly) to the 150k-tet
+    sample and names the reason; the line still carries headline, roofline and parity, status 0."""
+    out = _run("--gpus", "1", "--steps", "200", "--warmup", "20", "--budget-s", "75")
+    assert out["legs"]["headline"] == "done" and out["legs"]["roofline"] == "done"
+    base = out["cpu_baseline"]
+    assert "fallback" in base and "n=10" in base["sample"] and base["value"] > 0
+    assert out["parity"]["rel_l2"] < 1e-10 and "n=10" in out["parity"]["mesh"]
+    assert out["leg_seconds"]["total"] < 75
