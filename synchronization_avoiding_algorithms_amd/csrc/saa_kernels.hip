@@ -834,6 +834,19 @@ __global__ void __launch_bounds__(SAA_LB) persistent_steps_kernel(DeviceMesh m, 
   const int n_post = n_ir_pad + (bd.n_elem - bd.n_interior);
   double tn = a.tn0;
   double sink = 0.0;
+  // The work items of a lane are the same in every step of the launch: the one of the first round and the first two of
+  // the second phase stay in registers (two each) instead of being read from LDS again - not for the read's bandwidth
+  // but for its round trip, which every wave sat out right behind a barrier, twice per step, before it could request a
+  // single node record.  (Made opaque once per step below: otherwise the compiler hoists their unpacking - fifteen more
+  // registers - out of the step loop as well.)
+  const uint2 kNullItem = {0u, 2u << 28};
+  uint2 w_first = tid < n_pre ? connl[tid] : kNullItem, w_post[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int p = tid + j * nt;
+    const int e = p < n_ir_pad ? (p < n_ir ? n_pre + p : -1) : (p < n_post ? bd.n_interior + (p - n_ir_pad) : -1);
+    w_post[j] = e >= 0 ? connl[e] : kNullItem;
+  }
 #ifdef SAA_PERSIST_STAMPS
   unsigned long long T[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tk = stamp();
 #define PSTAMP(j) { const unsigned long long t_ = stamp(); T[j] += t_ - tk; tk = t_; }
@@ -878,11 +891,10 @@ __global__ void __launch_bounds__(SAA_LB) persistent_steps_kernel(DeviceMesh m, 
         }
       }
     };
-    // (interior items: the variant of the item code without ownership tests)
-    if (tid < n_pre)
-      item_forces<0, decltype(fetch), true>(connl[tid], rec, acc, bd.n_owned, m.lambda6, m.mu6, tid, sink, nullptr, fetch);
-    else
-      fetch();
+    // (interior items: the variant of the item code without ownership tests; a lane without an item of this round holds
+    // the null item, which only runs the hook)
+    asm volatile("" : "+v"(w_first.x), "+v"(w_first.y), "+v"(w_post[0].x), "+v"(w_post[0].y), "+v"(w_post[1].x), "+v"(w_post[1].y));
+    item_forces<0, decltype(fetch), true>(w_first, rec, acc, bd.n_owned, m.lambda6, m.mu6, tid, sink, nullptr, fetch);
     PSTAMP(0)
     PSTAMP(1)
     // ---- 2. halo displacements -> LDS (an entry still carrying an older stamp is simply read again) ------
@@ -930,7 +942,9 @@ __global__ void __launch_bounds__(SAA_LB) persistent_steps_kernel(DeviceMesh m, 
     //         (the ownership-test-free variant of the interior items, which the first round and the fused kernel use,
     //         was measured here too, behind a wave-uniform branch: 8.60-8.67 against 8.43 us/step in round 2, 8.06 against
     //         8.03 in round 3 with 104 instead of 112 registers in use)
-    for (int p = tid; p < n_post; p += nt) {
+    if (tid < n_post) item_forces<0>(w_post[0], rec, acc, bd.n_owned, m.lambda6, m.mu6, tid, sink);
+    if (tid + nt < n_post) item_forces<0>(w_post[1], rec, acc, bd.n_owned, m.lambda6, m.mu6, tid, sink);
+    for (int p = tid + 2 * nt; p < n_post; p += nt) {  // (blocks with more than two sweeps in this phase)
       const int e = p < n_ir_pad ? (p < n_ir ? n_pre + p : -1) : bd.n_interior + (p - n_ir_pad);
       if (e >= 0) item_forces<0>(connl[e], rec, acc, bd.n_owned, m.lambda6, m.mu6, tid, sink);
     }
