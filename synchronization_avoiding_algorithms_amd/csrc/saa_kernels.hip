@@ -1035,14 +1035,11 @@ __global__ void __launch_bounds__(SAA_LB) persistent_steps_kernel(DeviceMesh m, 
     const long long t_push = wall_clock64();  // ticks of the 100 MHz wall clock (a stand-in for xGMI's delivery time)
 #endif
     // (one dof at a time: requesting the operands of a lane's two or three dofs up front and interleaving their
-    // division chains was measured - 9.35 against 8.95 us/step at 1M tets, the extra live registers cost more than the
-    // exposed LDS round trips)
-    for (int i = ltid; i < n_own3; i += nt) {
-      const int n = i / 3, c = i - 3 * n;
-      const double u = rec[6 * n + 3 + c];
-      const int32_t tag = tagl[n];
-      if (PEER && (tag & kTagShared)) continue;  // below, from the force summed over the ranks
-      double v = cd_update_dof(acc[i], c == 0 ? 0.0 : fextl[n], massl[n], u, dnl[i], k);
+    // division chains was measured - 9.35 against 8.95 us/step at 1M tets in round 2, 7.99 against 7.87 in round 3 with
+    // the first two dofs of a lane as a pair)
+    auto update_dof = [&](int i, int n, int c, double u, int32_t tag, double f, double fe, double ma, double dnv) {
+      if (PEER && (tag & kTagShared)) return;  // below, from the force summed over the ranks
+      double v = cd_update_dof(f, fe, ma, u, dnv, k);
       if (tag & (1 << c)) v = 0.0;  // d1[Local_Dirichlet] = 0   (Dynamic_solver.py:20)
       if (PREDICT && (tag & kTagShared)) {
         // predicted phase: d1[loc_dof_shared] = prediction, recorded as history (Online_predictor.py:298,301)
@@ -1051,6 +1048,10 @@ __global__ void __launch_bounds__(SAA_LB) persistent_steps_kernel(DeviceMesh m, 
         if (aq->hist != nullptr) aq->hist[(aq->hist_row0 + s) * w + j] = v;
       }
       commit(i, n, c, u, v);
+    };
+    for (int i = ltid; i < n_own3; i += nt) {
+      const int n = i / 3, c = i - 3 * n;
+      update_dof(i, n, c, rec[6 * n + 3 + c], tagl[n], acc[i], c == 0 ? 0.0 : fextl[n], massl[n], dnl[i]);
     }
     if (PEER) {
       for (int j = ltid; j < n_sh3; j += nt) {
