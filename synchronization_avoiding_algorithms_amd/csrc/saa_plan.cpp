@@ -179,11 +179,6 @@ int32_t build_items(const std::vector<uint16_t> &loc, int32_t n_elem, int32_t n_
     apex_first(f, nbk[4 * static_cast<size_t>(e) + k], B);
     return compatible(A, B) ? f : -1;
   };
-  auto degree = [&](int32_t e) {
-    int d = 0;
-    for (int k = 0; k < 4; ++k) d += partner(e, k) >= 0;
-    return d;
-  };
   items.clear();
   items.reserve(8 * static_cast<size_t>(n_elem));
   int32_t n_items = 0;
@@ -203,16 +198,23 @@ int32_t build_items(const std::vector<uint16_t> &loc, int32_t n_elem, int32_t n_
     items.insert(items.end(), it, it + 8);
     ++n_items;
   };
-  // Greedy matching in a SPATIAL order of the elements, cell by cell of a grid of the mesh size (cells in lexicographic
-  // order, the elements of a cell by the shape key of their cheapest pair): an element takes the free partner that has the
-  // fewest other options left, ties broken by shape - the vector between the two centroids and the vector between the two
-  // apices in units of half a mesh size, made independent of which element is named first.  In the order of the caller's
-  // element list (what this loop used before) a mesh numbered at random left 5 % of its elements single - 7 % more work
-  // items than the same mesh numbered cell by cell - and paired equal cells differently, so that the pattern classes of
-  // the LDS packing could not form.  Measured alternatives on the 1M-tet beams (pairs found / items in clash-free halves
-  // by construction, structured | jittered and shuffled): list order 99.9 % / 58 % | 94.8 % / 31 %; fewest-options-first
-  // (Karp-Sipser) with shape ties 99.8 % / 43 % | 99.5 % / 37 %: best matching, but its fronts run inwards from the block
-  // faces and pair equal cells differently; shape by shape, most frequent first: a third of the elements single.
+  // Greedy matching in a SPATIAL order of the elements (xl given), else in the order of the caller's list: an element
+  // takes the free face neighbour that has the fewest other free neighbours left, ties broken by the pair's shape.
+  //   * order: cell by cell of a grid of the mesh size h (cells lexicographic; an element belongs to the cell of the
+  //     lowest corner of its bounding box), inside a cell by where the element's centroid sits in it - first the ORDER of
+  //     its three offsets from the cell corner (six patterns: the six tets of a Kuhn cube), then the offsets in quarters
+  //     of a cell - so that the tets of every cube come up in the same order and meet the same situation;
+  //   * shape of a candidate pair: the vector between the two centroids in quarters of h and the vector between the two
+  //     apices in units of h, made independent of which element is named first - coarse enough to be the same for nodes
+  //     moved off their lattice positions by a fifth of a cell (in halves of h the keys of a jittered lattice were noise,
+  //     and ties broken by noise pair equal cubes differently: 48 % of the items in pattern classes instead of 59 %).
+  // In the order of the caller's list (what this loop used before) a mesh numbered at random left 5 % of its elements
+  // single - 7 % more work items than the same mesh numbered cell by cell - and paired equal cells differently, so that
+  // the pattern classes of the LDS packing could not form.  Measured alternatives on the 1M-tet beams (pairs found / items
+  // in clash-free halves by construction, structured | jittered and shuffled): list order 99.9 % / 58 % | 94.8 % / 31 %;
+  // this order 99.8 % / - | 99.2 % / 59 %; fewest-options-first (Karp-Sipser) with shape ties 99.8 % / 43 % | 99.5 % /
+  // 37 %: best matching, but its fronts run inwards from the block faces and pair equal cells differently; shape by
+  // shape, most frequent first: a third of the elements single.
   std::vector<uint64_t> ekey(4 * static_cast<size_t>(n_elem), 0), ekey_min;
   if (xl != nullptr && h > 0.0) {
     auto centroid = [&](int32_t e, double c[3]) {
@@ -233,8 +235,8 @@ int32_t build_items(const std::vector<uint16_t> &loc, int32_t n_elem, int32_t n_
         const double *af = xl + 3 * static_cast<size_t>(loc[4 * static_cast<size_t>(f) + kf]);
         int q[6];
         for (int j = 0; j < 3; ++j) {
-          q[j] = static_cast<int>(std::lround(2.0 * (cf[j] - ce[j]) / h));
-          q[3 + j] = static_cast<int>(std::lround(2.0 * (af[j] - ae[j]) / h));
+          q[j] = static_cast<int>(std::lround(4.0 * (cf[j] - ce[j]) / h));
+          q[3 + j] = static_cast<int>(std::lround((af[j] - ae[j]) / h));
         }
         int sign = 0;
         for (int j = 0; j < 6 && sign == 0; ++j) sign = q[j] > 0 ? 1 : (q[j] < 0 ? -1 : 0);
@@ -246,8 +248,9 @@ int32_t build_items(const std::vector<uint16_t> &loc, int32_t n_elem, int32_t n_
   }
   std::vector<int32_t> order(n_elem);
   std::iota(order.begin(), order.end(), 0);
+  std::vector<uint64_t> okey;  // cell of every element (spatial variant only)
   if (xl != nullptr && h > 0.0) {
-    std::vector<uint64_t> okey(n_elem);
+    okey.resize(n_elem);
     double lo[3] = {1e300, 1e300, 1e300};
     for (int32_t e = 0; e < n_elem; ++e)
       for (int a = 0; a < 4; ++a)
@@ -261,9 +264,20 @@ int32_t build_items(const std::vector<uint16_t> &loc, int32_t n_elem, int32_t n_
         for (int a = 0; a < 4; ++a) mn = std::min(mn, xl[3 * static_cast<size_t>(loc[4 * static_cast<size_t>(e) + a]) + j]);
         cell = (cell << 16) | static_cast<uint64_t>(static_cast<int>(std::floor((mn - lo[j]) / h + 0.25)) & 0xffff);
       }
-      uint64_t best = ~0ull;
-      for (int k = 0; k < 4; ++k)
-        if (nb[4 * static_cast<size_t>(e) + k] >= 0) best = std::min(best, ekey[4 * static_cast<size_t>(e) + k]);
+      // inside a cell: by where the element's centroid sits in it (eighths of a cell), so that the tets of every cube
+      // come in the same order
+      // (first by the ORDER of the centroid's three offsets from the cell corner - which is largest, which smallest: six
+      // patterns, one per tet of a Kuhn cube, and the same for a node moved by a fifth of a cell - then by the offsets in
+      // quarters of a cell)
+      double off[3];
+      for (int j = 0; j < 3; ++j) {
+        double c = 0.0;
+        for (int a = 0; a < 4; ++a) c += 0.25 * xl[3 * static_cast<size_t>(loc[4 * static_cast<size_t>(e) + a]) + j];
+        off[j] = (c - (lo[j] + h * static_cast<double>((cell >> (16 * j)) & 0xffff))) / h;
+      }
+      uint64_t best = static_cast<uint64_t>((off[0] > off[1]) + 2 * (off[1] > off[2]) + 4 * (off[0] > off[2]));
+      for (int j = 2; j >= 0; --j)
+        best = (best << 8) | static_cast<uint64_t>(static_cast<int>(std::floor(4.0 * off[j] + 0.5)) & 0xff);
       okey[e] = cell;
       ekey_min.push_back(best);
     }
@@ -281,10 +295,10 @@ int32_t build_items(const std::vector<uint16_t> &loc, int32_t n_elem, int32_t n_
       const int32_t f = partner(e, k);
       if (f < 0) continue;
       used[e] = 1;  // (f's options without e; the list-order variant counts every free neighbour, as it always has)
-      const int df = xl != nullptr ? degree(f) : free_degree(f);
+      const int df = free_degree(f);
       used[e] = 0;
       const uint64_t kk = ekey[4 * static_cast<size_t>(e) + k];
-      if (df < best_deg || (df == best_deg && kk < best_key)) {  // the neighbour with the fewest other options, then by shape
+      if (df < best_deg || (df == best_deg && kk < best_key)) {
         best_deg = df;
         best_key = kk;
         best_k = k;
@@ -634,7 +648,7 @@ void block_axis_order(const double *xyz, const int32_t *new_to_old, int32_t n_ow
 // the halo list), so that boundary items fall into classes too.  On a jittered lattice this restores the classes of the
 // undisturbed one; on a genuinely unstructured mesh it yields them wherever the mesh is locally regular.
 struct LatticeColours {
-  double lo[3], h;
+  double lo[3], h;  // lo: the lattice plane the lowest owned node rounds to
   int ext[3], axis[3];
   // residue class (mod 32) of a position
   int operator()(const double *x) const {
@@ -647,15 +661,24 @@ LatticeColours lattice_colours(const double *xyz, const int32_t *new_to_old, int
   static const int kPerm[6][3] = {{0, 1, 2}, {0, 2, 1}, {1, 0, 2}, {1, 2, 0}, {2, 0, 1}, {2, 1, 0}};
   LatticeColours lc;
   lc.h = h;
-  double hi[3] = {-1e300, -1e300, -1e300};
-  for (int k = 0; k < 3; ++k) lc.lo[k] = 1e300;
+  // Where the lattice planes lie along each axis: the PHASE of the node coordinates modulo h, as the circular mean
+  // of x/h - the mean over all nodes of the block, so that nodes moved off their lattice position by a fifth of a cell
+  // in either direction leave it where it was; taking the lowest node as the origin would shift every rounding
+  // boundary by that node's own displacement and put a tenth of the nodes into the wrong cell (each of them sits in
+  // seventeen items, which then fall out of their classes).  A mesh without any lattice has no phase; any value does.
+  double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300}, sn[3] = {0, 0, 0}, cs[3] = {0, 0, 0};
+  const double two_pi = 6.283185307179586;
   for (int32_t l = 0; l < n_owned; ++l)
     for (int k = 0; k < 3; ++k) {
       const double v = xyz[3 * static_cast<int64_t>(new_to_old[l]) + k];
-      lc.lo[k] = std::min(lc.lo[k], v);
+      lo[k] = std::min(lo[k], v);
       hi[k] = std::max(hi[k], v);
+      sn[k] += std::sin(two_pi * v / h);
+      cs[k] += std::cos(two_pi * v / h);
     }
   for (int k = 0; k < 3; ++k) {
+    const double phase = h * std::atan2(sn[k], cs[k]) / two_pi;                // planes at phase + m h
+    lc.lo[k] = phase + h * std::floor((lo[k] - phase) / h + 0.5);             // the plane the lowest node rounds to
     lc.ext[k] = static_cast<int>(std::floor((hi[k] - lc.lo[k]) / h + 0.5)) + 1;
     lc.axis[k] = kPerm[variant % 6][k];
   }

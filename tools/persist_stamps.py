@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from _diag import use_diag_library  # noqa: E402
 
 use_diag_library(["-DSAA_PERSIST_STAMPS"])  # diagnostic build of the library; the product .so has none of the saa_debug_* entry points
-from bench import build_rank_solver  # noqa: E402
+from bench import bench_mesh, build_rank_solver  # noqa: E402
 from synchronization_avoiding_algorithms_amd.mesh import structured_beam  # noqa: E402
 
 # usage: persist_stamps.py [n [parts rank [peer]]]   (parts > 1: the x-slab partition `rank` of `parts`; exchange-free steps,
@@ -22,7 +22,7 @@ parts = int(pos[1]) if len(pos) > 1 else 1
 prank = int(pos[2]) if len(pos) > 2 else 0
 peer = len(pos) > 3 and pos[3] == "peer"
 steps = 1000
-mesh = structured_beam(n)
+mesh = bench_mesh(n, "jittered") if "--mesh=jittered" in sys.argv else structured_beam(n)
 sol, lay, _, _ = build_rank_solver(mesh, parts, prank, 0)
 st = sol.plan_stats()
 waves = st["n_blocks"] * st["threads"] // 64
