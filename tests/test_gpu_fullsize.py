@@ -110,6 +110,44 @@ def test_config2_one_million_tets_resident_and_fused_kernels():
     sol.close()
 
 
+def test_one_million_tets_with_jittered_nodes_and_shuffled_numbering():
+    """The workload of ``bench.py --mesh jittered``: the same beam with every interior node moved by up to 20 % of a cell
+    and nodes and elements numbered at random - the plan pairs its elements in a spatial order and gives the blocks a
+    pseudo-lattice numbering with re-ordered halo lists (saa_plan.cpp), paths a lattice never takes.  Operator
+    properties and 100 steps of both kernels against the oracle on that mesh (positive and distorted elements alike)."""
+    import sys
+
+    from conftest import REPO
+    from oracle import fem_oracle as fo
+
+    sys.path.insert(0, REPO)
+    argv, sys.argv = sys.argv, ["bench.py"]
+    try:
+        from bench import bench_mesh
+    finally:
+        sys.argv = argv
+    mesh = bench_mesh(19, "jittered")
+    sol, lay, dt, l_M, F, (lmd, mu) = _build(mesh, 1, 0)
+    st = sol.plan_stats()
+    assert st["n_blocks"] == 256 and sol.resident_kernel_info()["capable"]
+    assert st["n_by_construction"] > 0.5 * st["n_items"] and st["n_pairs"] > 0.985 * st["n_elem_copies"] / 2, st
+    K = fo.MatrixFreeStiffness(lay.cells_local, mesh.points[lay.nodes], lmd, mu)
+    rng = np.random.default_rng(7)
+    _operator_properties(sol, K, mesh.points[lay.nodes], rng)
+    d0, dn = _rough_state(sol.n_dof, lay.dirichlet_dofs, rng)
+    tn, o0, on = 0.25, d0, dn
+    for _ in range(100):
+        o1 = fo.explicit_step(K, F, lay.dirichlet_dofs, tn, dt, o0, on, l_M, ALPHA)
+        on, o0, tn = o0, o1, tn + dt
+    for name, resident in (("resident", True), ("fused", False)):
+        sol.set_resident_kernel(resident)
+        sol.set_state(d0, dn, 0.25)
+        sol.step(100)
+        g0, gn, gt = sol.get_state()
+        assert gt == tn and rel_l2(g0, o0) < 1e-11 and rel_l2(gn, on) < 1e-11, name
+    sol.close()
+
+
 def test_config3_middle_slab_of_the_8gpu_partition_through_the_peer_exchange():
     import torch
     from oracle import fem_oracle as fo
