@@ -259,6 +259,35 @@ int saa_synchronize(saa_solver *s);
  * timing code at all: BASELINE.md section 1). */
 int saa_device_copy_bandwidth(int32_t device, int64_t n_bytes, int32_t reps, double *bytes_per_s);
 
+/*
+ * Shared-node predictor: the per-rank LSTM encoder-decoder of Tools/DNN_tools.py:16-98 (2-layer bidirectional encoder of
+ * width hidden_size, decoder LSTM of width 2*hidden_size + Linear) evaluated for all filter_size phase offsets of one
+ * prediction window - what Tools/DNN_prediction.py:38-55 (`encoder_decoder_predictor`) computes with filter_size
+ * sequential batch-1 passes on the CPU - as four launches (two f32 matrix-core GEMMs for the input projections, one
+ * recurrence kernel, one output GEMM that scales back and writes the table).
+ *
+ * saa_predictor_create replaces `call_model` (DNN_prediction.py:18-34): `weights` are host pointers to the 22 fp32
+ * tensors of the reference's state_dict in ITS order (Model_training.py:179-180 saves them):
+ *   encoder.lstm_encoder.{weight_ih, weight_hh, bias_ih, bias_hh}_l0, the same four _l0_reverse, _l1, _l1_reverse,
+ *   decoder.lstm_decoder.{weight_ih, weight_hh, bias_ih, bias_hh}_l0, decoder.fc.weight, decoder.fc.bias
+ * (row-major, PyTorch's gate order i, f, g, o).  They are copied; the caller may free them after the call.
+ * filter_size >= 2, hidden_size <= 128.
+ */
+typedef struct saa_predictor saa_predictor;
+int saa_predictor_create(int32_t device, int32_t input_size, int32_t hidden_size, int32_t n_past, int32_t n_future,
+                         int32_t filter_size, const float *const *weights, int32_t n_weights, saa_predictor **out);
+
+/* `encoder_decoder_predictor(device, n, model, n_p, n_f, n_s, input_size, d_sol, scale_max, scale_min)`
+ * (DNN_prediction.py:38-55) on device buffers: reads rows [n - n_past*filter_size, n) of the fp64 history `hist_dev`
+ * (hist_rows x input_size, row stride ld_hist doubles: d_sol of Online_predictor.py:260,301), scales them to [-1, 0]
+ * (DNN_tools.py:272-275), runs the model in fp32 and writes the (filter_size*n_future) x input_size fp64 table (row stride
+ * ld_table) whose row k is the prediction for step n + k (`NF`, DNN_prediction.py:45,53-54; what saa_step_predicted
+ * consumes).  Enqueued on `stream` (a hipStream_t; null = the null stream); returns without synchronising. */
+int saa_predictor_predict(saa_predictor *p, const double *hist_dev, int64_t hist_rows, int64_t ld_hist, int64_t n,
+                          double scale_max, double scale_min, double *table_dev, int64_t ld_table, void *stream);
+
+int saa_predictor_destroy(saa_predictor *p);
+
 /* Timing aid for bench.py: runs `nsteps` saa_step steps bracketed by HIP events recorded on the
  * handle's stream and returns the elapsed milliseconds (kernel time incl. launch gaps). */
 int saa_time_steps(saa_solver *s, int32_t nsteps, double *elapsed_ms);

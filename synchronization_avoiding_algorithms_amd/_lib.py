@@ -17,10 +17,10 @@ LIB_PATH = os.environ.get("SAA_LIB_PATH") or os.path.join(_HERE, "libsaa_hip.so"
 #: only; built on request (``build_library(diag=True)``), loaded through SAA_LIB_PATH, never by the package itself
 DIAG_LIB_PATH = os.path.join(_HERE, "libsaa_hip_diag.so")
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "saa_hip.h")
-SOURCES = ["saa_plan.cpp", "saa_partition.cpp", "saa_kernels.hip", "saa_setup.hip", "saa_api.cpp"]
+SOURCES = ["saa_plan.cpp", "saa_partition.cpp", "saa_kernels.hip", "saa_setup.hip", "saa_predictor.hip", "saa_api.cpp"]
 HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics", "-ldl"]
 
-ABI_VERSION = 7  # what saa_abi_version() of a matching library returns (include/saa_hip.h)
+ABI_VERSION = 8  # what saa_abi_version() of a matching library returns (include/saa_hip.h)
 SAA_OK, SAA_E_ARG, SAA_E_HIP, SAA_E_STATE, SAA_E_CAPACITY = 0, -1, -2, -3, -4
 
 
@@ -109,6 +109,11 @@ SIGNATURES = {
     "saa_synchronize": (C.c_int, [_H]),
     "saa_time_steps": (C.c_int, [_H, C.c_int32, _dp]),
     "saa_device_copy_bandwidth": (C.c_int, [C.c_int32, C.c_int64, C.c_int32, _dp]),
+    "saa_predictor_create": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                       C.POINTER(C.POINTER(C.c_float)), C.c_int32, C.POINTER(_H)]),
+    "saa_predictor_predict": (C.c_int, [_H, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_double, C.c_double,
+                                        C.c_void_p, C.c_int64, C.c_void_p]),
+    "saa_predictor_destroy": (C.c_int, [_H]),
 }
 
 _lib = None

@@ -18,6 +18,7 @@
 #include "saa_device.h"
 #include "saa_partition.h"
 #include "saa_plan.h"
+#include "saa_predictor.h"
 #include "saa_setup.h"
 
 namespace {
@@ -635,7 +636,7 @@ extern "C" {
 
 const char *saa_last_error(void) { return g_last_error.c_str(); }
 
-int32_t saa_abi_version(void) { return 7; }  // 4: saa_part_mesh_kway, saa_setup_fields; 5: saa_set_deterministic; 6: saa_device_copy_bandwidth; 7: saa_plan_stats grew
+int32_t saa_abi_version(void) { return 8; }  // 4: saa_part_mesh_kway, saa_setup_fields; 5: saa_set_deterministic; 6: saa_device_copy_bandwidth; 7: saa_plan_stats grew; 8: saa_predictor_*
 
 int saa_device_copy_bandwidth(int32_t device, int64_t n_bytes, int32_t reps, double *bytes_per_s) {
   if (!bytes_per_s || n_bytes < 16 || reps < 1) return fail(SAA_E_ARG, "saa_device_copy_bandwidth: bad argument");
@@ -1501,6 +1502,56 @@ int saa_time_steps(saa_solver *s, int32_t nsteps, double *elapsed_ms) {
   (void)hipEventDestroy(a);
   (void)hipEventDestroy(b);
   return rc;
+}
+
+// ---- shared-node predictor (saa_predictor.hip) ----------------------------------------------------------------
+struct saa_predictor {
+  saa::Predictor *impl = nullptr;
+};
+
+int saa_predictor_create(int32_t device, int32_t input_size, int32_t hidden_size, int32_t n_past, int32_t n_future,
+                         int32_t filter_size, const float *const *weights, int32_t n_weights, saa_predictor **out) {
+  if (!out) return fail(SAA_E_ARG, "saa_predictor_create: null output");
+  *out = nullptr;
+  if (n_weights != saa::kPredictorWeights)
+    return fail(SAA_E_ARG, "saa_predictor_create: expected the 22 tensors of the reference's state_dict");
+  std::string err;
+  saa::Predictor *impl = nullptr;
+  const saa::PredictorShape sh{input_size, hidden_size, n_past, n_future, filter_size};
+  const hipError_t e = saa::predictor_create(device, sh, weights, &impl, err);
+  if (e != hipSuccess)
+    return err.empty() ? fail(SAA_E_HIP, std::string("saa_predictor_create: ") + hipGetErrorString(e)) : fail(SAA_E_ARG, err);
+  saa_predictor *p = new (std::nothrow) saa_predictor;
+  if (!p) {
+    saa::predictor_destroy(impl);
+    return fail(SAA_E_HIP, "saa_predictor_create: out of host memory");
+  }
+  p->impl = impl;
+  *out = p;
+  return SAA_OK;
+}
+
+int saa_predictor_predict(saa_predictor *p, const double *hist_dev, int64_t hist_rows, int64_t ld_hist, int64_t n,
+                          double scale_max, double scale_min, double *table_dev, int64_t ld_table, void *stream) {
+  if (!p || !p->impl || !hist_dev || !table_dev) return fail(SAA_E_ARG, "saa_predictor_predict: null argument");
+  const saa::PredictorShape &sh = saa::predictor_shape(p->impl);
+  const int64_t window = (int64_t)sh.n_past * sh.filter;
+  if (ld_hist < sh.input_size || ld_table < sh.input_size)
+    return fail(SAA_E_ARG, "saa_predictor_predict: row stride below input_size");
+  if (n < window || n > hist_rows)
+    return fail(SAA_E_ARG, "saa_predictor_predict: rows [n - n_past*filter, n) are not inside the history");
+  if (!(scale_max - scale_min != 0.0)) return fail(SAA_E_ARG, "saa_predictor_predict: scale_max == scale_min");
+  HIP_TRY(hipSetDevice(saa::predictor_device(p->impl)));
+  HIP_TRY(saa::predictor_predict(p->impl, hist_dev, ld_hist, n, scale_max, scale_min, table_dev, ld_table,
+                                 static_cast<hipStream_t>(stream)));
+  return SAA_OK;
+}
+
+int saa_predictor_destroy(saa_predictor *p) {
+  if (!p) return SAA_OK;
+  saa::predictor_destroy(p->impl);
+  delete p;
+  return SAA_OK;
 }
 
 #ifdef SAA_DIAGNOSTICS

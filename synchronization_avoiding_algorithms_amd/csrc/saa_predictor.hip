@@ -1,0 +1,622 @@
+// Shared-node predictor for gfx950: the reference's per-rank LSTM encoder-decoder (Tools/DNN_tools.py:16-98), evaluated
+// for ALL phase offsets of a prediction window at once (Tools/DNN_prediction.py:38-55 runs them one by one on the CPU).
+//
+// What one window needs, for n_s phases i, n_p history rows per phase (row i + n_s*j of the window, j < n_p):
+//   1. the input projection of encoder layer 0, both directions: the window's n_p*n_s history rows are every row of
+//      hist[n - n_p*n_s, n) exactly once, so it is ONE GEMM  (n_p*n_s x I) . (I x 8H)  on the f32 matrix cores - the
+//      fp64 history scaled to [-1, 0] (DNN_tools.py:272-275) and rounded to fp32 on its way into LDS;
+//   2. the decoder's first step takes the last history row of each phase: a second, small GEMM  (n_s x I) . (I x 8H);
+//   3. the recurrences (two encoder layers, both directions; n_f decoder steps): one workgroup per phase.  The decoder's
+//      later steps feed its own output back (DNN_tools.py:226-231): inp = fc(h), gates = inp W_ih^T + h W_hh^T + b, which
+//      is  h (W_ih W_fc + W_hh)^T + (W_ih b_fc + b)  - the folded matrix is formed once per model (in fp64, rounded to
+//      fp32), so no step of the recurrence touches a matrix with an I-sized side;
+//   4. all n_f outputs of all phases at once: (n_f*n_s x 2H) . (2H x I) + bias, scaled back in fp32 (DNN_tools.py:277-279)
+//      and widened into the fp64 table whose row k is the prediction for step n + k (DNN_prediction.py:45,53-54).
+// fp32 arithmetic like the reference (.float() at DNN_prediction.py:49); sums are taken in another order than ATen's,
+// so results agree to fp32 round-off, not bit for bit (tests/test_gpu_predictor.py states the tolerance).
+#include "saa_predictor.h"
+
+#include <algorithm>
+#include <cmath>
+#include <type_traits>
+#include <vector>
+
+namespace saa {
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------------------------
+// C = A . B^T on v_mfma_f32_16x16x4_f32 (exact f32).  A: M x K (fp64 scaled on load, or fp32), B: N x ldb fp32 with rows
+// zero-padded to a multiple of 32.  Workgroup: 256 threads = 4 waves, 64 rows x 208 columns of C; a wave holds 16 rows x
+// 13 tiles of 16 columns (52 accumulator registers).  TWO workgroups per CU, i.e. two waves per SIMD that are NOT in
+// lock-step: while one stores its next chunk and waits at its barrier the other multiplies (eight waves of one workgroup
+// reach every barrier together and the matrix cores idle: 55 TFLOP/s against 45 with the compiler's own schedule).
+// What a wave needs of a chunk - two b128 reads of A, twenty-six of B - is requested in one go and the MFMAs run tile
+// after tile on independent accumulators; fences keep that order in the binary (left alone the compiler reads one
+// fragment, waits, and issues four dependent MFMAs, thirteen times per group).
+// K in chunks of 32 through LDS, row stride 40 floats = ten 16-byte slots: ds_read_b128 serves four groups of sixteen
+// lanes - {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and the same + 32 - and with ten slots per row the sixteen lanes of
+// each group fall on sixteen different slots of the 256-byte bank row (nine slots, the usual "stride 36", are 2-way).
+// The next chunk travels global -> registers during the MFMAs of the current one.  A lane's four k of a b128 read go to
+// four MFMAs, i.e. MFMA s of a group of sixteen k sums k = s, 4+s, 8+s, 12+s - any assignment does as long as A and B use
+// the same one.
+// Split-K over blockIdx.z: partial sums go to Cpart[z] and are added by their reader in a fixed order (deterministic).
+// ---------------------------------------------------------------------------------------------
+constexpr int kBM = 64, kKC = 32, kLd = 40, kT = 13, kBN = 16 * kT, kGemmThreads = 256;
+constexpr size_t kGemmLds = (size_t)(kBM + kBN) * kLd * sizeof(float);  // 43.5 KB
+
+struct GemmArgs {
+  const void *A;
+  int64_t lda;
+  const float *B;
+  int64_t ldb;
+  int M, N, K, k_per_split;
+  double smax, sden;  // A_F64: a = (float)((x - smax) / sden)
+  float *Cpart;       // !TABLE: [splits][M][ldc]
+  int64_t ldc;
+  const float *bias;  // TABLE: table[m][n] = (double)((acc + bias[n]) * range32 + max32), two fp32 roundings
+  float range32, max32;
+  double *table;
+  int64_t ldt;
+#ifdef SAA_GEMM_STAMPS
+  unsigned long long *stamps;  // tools/gemm_stamps.hip: [workgroup][wave][8] cycles per segment of the chunk loop
+#endif
+};
+
+template <bool A_F64, bool TABLE>
+__global__ void __launch_bounds__(kGemmThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) gemm_nt_kernel(GemmArgs g) {
+  using AT = typename std::conditional<A_F64, double, float>::type;
+  extern __shared__ __attribute__((aligned(16))) float gemm_lds[];
+  float *As = gemm_lds, *Bs = gemm_lds + kBM * kLd;
+  const int tid = threadIdx.x, lane = tid & 63, wm = tid >> 6;
+  const int m0 = blockIdx.x * kBM, n0 = blockIdx.y * kBN;
+  const int kbeg = blockIdx.z * g.k_per_split, kend = min(g.K, kbeg + g.k_per_split);
+  constexpr int kAq = kBM * kKC / kGemmThreads;                             // 8 elements of A per thread and chunk
+  constexpr int kBq = (kBN * (kKC / 4) + kGemmThreads - 1) / kGemmThreads;  // 7 x 16 bytes of B (the last sweep half empty)
+  f32x4 acc[kT];
+#pragma unroll
+  for (int t = 0; t < kT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // (staging registers as ext-vector types and the lambdas force-inlined: an array of HIP's float4 structs, or a lambda
+  // called from two places and therefore not inlined, leaves them in scratch memory - one load at a time, each waited for)
+  AT areg[kAq];
+  f32x4 breg[kBq];
+  // (unconditional loads at clamped indices; what lies outside is zeroed when it is stored)
+  auto load_chunk = [&](int k0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int q = 0; q < kAq; ++q) {
+      const int e = tid + kGemmThreads * q, row = e >> 5, kk = e & 31;
+      const int gm = min(m0 + row, g.M - 1), gk = min(k0 + kk, g.K - 1);
+      areg[q] = static_cast<const AT *>(g.A)[(int64_t)gm * g.lda + gk];
+    }
+#pragma unroll
+    for (int q = 0; q < kBq; ++q) {
+      const int p = tid + kGemmThreads * q, r = min(p >> 3, kBN - 1), c4 = p & 7;
+      const int gn = min(n0 + r, g.N - 1);
+      breg[q] = *reinterpret_cast<const f32x4 *>(g.B + (int64_t)gn * g.ldb + k0 + 4 * c4);
+    }
+  };
+  auto store_chunk = [&](int k0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int q = 0; q < kAq; ++q) {
+      const int e = tid + kGemmThreads * q, row = e >> 5, kk = e & 31;
+      float v;
+      if (A_F64) v = (float)(((double)areg[q] - g.smax) / g.sden);  // DNN_tools.py:272-275 in fp64, then .float()
+      else v = (float)areg[q];
+      As[row * kLd + kk] = (m0 + row < g.M && k0 + kk < kend) ? v : 0.f;
+    }
+#pragma unroll
+    for (int q = 0; q < kBq; ++q) {
+      const int p = tid + kGemmThreads * q, r = p >> 3, c4 = p & 7;
+      if (p < kBN * (kKC / 4)) {
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4 *>(&Bs[r * kLd + 4 * c4]) = n0 + r < g.N ? breg[q] : z;
+      }
+    }
+  };
+  const float *ap = As + (16 * wm + (lane & 15)) * kLd + 4 * (lane >> 4), *bp = Bs + (lane & 15) * kLd + 4 * (lane >> 4);
+  auto multiply = [&]() __attribute__((always_inline)) {
+    f32x4 a0, a1, b0[kT], b1[kT];
+    a0 = *reinterpret_cast<const f32x4 *>(ap);
+#pragma unroll
+    for (int t = 0; t < kT; ++t) b0[t] = *reinterpret_cast<const f32x4 *>(bp + 16 * t * kLd);
+    a1 = *reinterpret_cast<const f32x4 *>(ap + 16);
+#pragma unroll
+    for (int t = 0; t < kT; ++t) b1[t] = *reinterpret_cast<const f32x4 *>(bp + 16 * t * kLd + 16);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int t = 0; t < kT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[s], b0[t][s], acc[t], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int t = 0; t < kT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[s], b1[t][s], acc[t], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+#ifdef SAA_GEMM_STAMPS
+  unsigned long long T[6] = {0, 0, 0, 0, 0, 0}, tk = __builtin_readcyclecounter();
+#define GSTAMP(j) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_readcyclecounter(); T[j] += t_ - tk; tk = t_; __builtin_amdgcn_sched_barrier(0); }
+#else
+#define GSTAMP(j)
+#endif
+  load_chunk(min(kbeg, max(kend - 1, 0)));
+  for (int k0 = kbeg; k0 < kend; k0 += kKC) {
+#ifdef SAA_GEMM_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    GSTAMP(5)
+#endif
+    store_chunk(k0);
+    GSTAMP(0)
+    __syncthreads();
+    GSTAMP(1)
+    // (unconditionally: behind the last chunk the slice's first chunk is fetched once more, unused - staging registers
+    // that are live across a branch end up in scratch memory as well)
+    load_chunk(k0 + kKC < kend ? k0 + kKC : kbeg);
+    GSTAMP(2)
+    multiply();
+    GSTAMP(3)
+    __syncthreads();
+    GSTAMP(4)
+  }
+#ifdef SAA_GEMM_STAMPS
+  if (lane == 0)
+    for (int j = 0; j < 6; ++j)
+      g.stamps[(((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 32 + wm * 8 + j] = T[j];
+#endif
+  // C/D layout of the 16x16 forms: column = lane & 15, row = 4 * (lane >> 4) + register
+#pragma unroll
+  for (int t = 0; t < kT; ++t) {
+    const int col = n0 + 16 * t + (lane & 15);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = m0 + 16 * wm + 4 * (lane >> 4) + r;
+      if (row < g.M && col < g.N) {
+        if (TABLE) {
+          const float y = __fadd_rn(__fmul_rn(__fadd_rn(acc[t][r], g.bias[col]), g.range32), g.max32);
+          g.table[(int64_t)row * g.ldt + col] = (double)y;
+        } else {
+          g.Cpart[((int64_t)blockIdx.z * g.M + row) * g.ldc + col] = acc[t][r];
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The recurrences of one phase: encoder layer 0 and 1 (forward and backward direction side by side), then the decoder.
+// Thread g < 8H owns one gate row (direction g / 4H of the encoder; the decoder's 4 * 2H rows), thread u < 2H one hidden
+// unit and its cell state.  Weights are stored transposed ([k][row]) so that a wave reads consecutive rows; they are the
+// same for every workgroup and come from the L2.  PyTorch's gate order (i, f, g, o) and its update
+// c = f c + i g,  h = o tanh(c)  (torch.nn.LSTM, used at DNN_tools.py:32,73).
+// ---------------------------------------------------------------------------------------------
+struct LstmArgs {
+  int H, n_p, n_f, n_s, S1, S2;
+  const float *P1;  // [S1][n_p*n_s][ld1]  partial input projections of encoder layer 0 (no bias)
+  int64_t ld1;
+  const float *P2;  // [S2][n_s][ld2]      partial input projections of the decoder's first step
+  int64_t ld2;
+  const float *b0, *Whh0t, *Wih1t, *Whh1t, *b1, *Wdhht, *bd, *Wcombt, *bcomb;
+  float *Hs;  // [n_f*n_s][ldh]  decoder states, row i + n_s*j
+  int64_t ldh;
+};
+
+__device__ __forceinline__ float sigmoid_f32(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// The weights of one gate row: N of them read once into registers (N > 0: plain local arrays and loops that unroll - an
+// array inside a struct stays in scratch memory), or any number streamed from the L2 on every use (N == 0, n at run time).
+// Element k is base[off + k * stride]: a wave-uniform base, a 32-bit lane offset and a stride that is a compile-time
+// constant when N > 0 - with a 64-bit pointer per lane the compiler forms all N addresses before the first load (2 N
+// registers) and spills.
+template <int N>
+__device__ __forceinline__ void col_load(float (&w)[N > 0 ? N : 1], const float *base, int off, int stride) {
+  if (N > 0) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      w[k] = base[off + k * stride];
+      if (k % 10 == 9) __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+template <int N>
+__device__ __forceinline__ float col_dot(const float (&w)[N > 0 ? N : 1], const float *base, int off, int stride, const float *h,
+                                         int n, float acc) {
+  if (N > 0) {  // four partial sums: one chain of N dependent FMAs is what a step of the recurrence would wait for
+    float p1 = 0.f, p2 = 0.f, p3 = 0.f;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      if (k % 4 == 0) acc = fmaf(h[k], w[k], acc);
+      else if (k % 4 == 1) p1 = fmaf(h[k], w[k], p1);
+      else if (k % 4 == 2) p2 = fmaf(h[k], w[k], p2);
+      else p3 = fmaf(h[k], w[k], p3);
+    }
+    acc = (acc + p1) + (p2 + p3);
+  } else {
+    for (int k = 0; k < n; ++k) acc = fmaf(h[k], base[off + k * stride], acc);
+  }
+  return acc;
+}
+constexpr int lstm_threads(int hc) { return hc > 0 ? (8 * hc + 63) / 64 * 64 : 1024; }
+
+// HC: the hidden size at compile time (weights in registers: a step of a recurrence then costs its FMAs and two barriers,
+// not a pass over the L2 - 5.2 us -> 0.7 us per step at H = 50, the reference's nH), or 0 for any size up to 128.
+template <int HC>
+__global__ void __launch_bounds__(lstm_threads(HC)) lstm_recurrence_kernel(LstmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int H = HC > 0 ? HC : a.H, H4 = 4 * H, G = 8 * H, D = 2 * H, n_p = a.n_p;
+  float *gates = sm;               // [G]
+  float *hbuf = gates + G;         // [D]   h of both directions / of the decoder
+  float *out0 = hbuf + D;          // [n_p][D]  outputs of layer 0: forward | backward (the input of layer 1)
+  float *pre1 = out0 + n_p * D;    // [n_p][G]  input projections of layer 0, then of layer 1
+  const int tid = threadIdx.x, i = blockIdx.x;
+  const bool gate_thread = tid < G, unit_thread = tid < D;
+  const int g = min(tid, G - 1), dir = g / H4, row = g - dir * H4;
+  const int ud = min(tid, D - 1) / H, uj = min(tid, D - 1) - ud * H;  // direction and index of this thread's unit
+  const int64_t M1 = (int64_t)n_p * a.n_s;
+  float c = 0.f;
+  // Every gate thread applies its gate's activation itself (rows [2H', 3H') of a block of 4H' rows are the cell candidate
+  // g: tanh; i, f, o: the logistic function), so that the unit threads, two waves of seven, are left with one tanh.
+  const bool enc_tanh = row >= 2 * H && row < 3 * H, dec_tanh = g >= 2 * D && g < 3 * D;
+  auto activate = [&](float v, bool is_tanh) { return is_tanh ? tanhf(v) : sigmoid_f32(v); };
+  auto encoder_cell = [&](int s, bool keep) {  // activated gates -> (c, h) of unit (ud, uj); time index of step s per direction
+    if (unit_thread) {
+      const float *q = gates + ud * H4 + uj;
+      c = q[H] * c + q[0] * q[2 * H];
+      const float hv = q[3 * H] * tanhf(c);
+      hbuf[tid] = hv;
+      if (keep) out0[(ud ? n_p - 1 - s : s) * D + tid] = hv;
+    }
+  };
+  // ---- encoder layer 0 (zero initial state).  Its input projections - bias + the split-K partial sums of GEMM 1, in a
+  //      fixed order - go to LDS first, all time steps at once (many loads in flight; a load inside the step loop is waited
+  //      for in every step) ---------------------------------------------------
+  if (unit_thread) hbuf[tid] = 0.f;
+  if (gate_thread) {
+    const float b = a.b0[g];
+    for (int t = 0; t < n_p; ++t) {
+      float v = b;
+      for (int z = 0; z < a.S1; ++z) v += a.P1[(z * M1 + (int64_t)t * a.n_s + i) * a.ld1 + g];
+      pre1[t * G + g] = v;
+    }
+  }
+  {
+    float w[HC > 0 ? HC : 1];
+    const int off = dir * H * H4 + row;
+    col_load<HC>(w, a.Whh0t, off, H4);
+    __syncthreads();
+    for (int s = 0; s < n_p; ++s) {
+      const float v = col_dot<HC>(w, a.Whh0t, off, H4, hbuf + dir * H, H, pre1[(dir ? n_p - 1 - s : s) * G + g]);
+      if (gate_thread) gates[g] = activate(v, enc_tanh);
+      __syncthreads();
+      encoder_cell(s, true);
+      __syncthreads();
+    }
+  }
+  // ---- encoder layer 1: input projections of all time steps first - a small GEMM (n_p x 2H) . (2H x 8H) on the matrix
+  //      cores: A from the layer-0 outputs in LDS, B straight from the (transposed) weights, a wave per 16 gate rows and
+  //      32 time steps.  (As FMAs against 2H weights per thread held in registers it spilled.) ----
+  {
+    const int lane = tid & 63, n_waves = blockDim.x >> 6, kq = lane >> 4, lj = lane & 15;
+    for (int ct = tid >> 6; 16 * ct < G; ct += n_waves) {
+      const int gc = min(16 * ct + lj, G - 1), cdir = gc / H4, crow = gc - cdir * H4;
+      const float *wp = a.Wih1t + cdir * D * H4 + crow;
+      for (int t0 = 0; t0 < n_p; t0 += 32) {
+        const float *xa = out0 + min(t0 + lj, n_p - 1) * D, *xb = out0 + min(t0 + 16 + lj, n_p - 1) * D;
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 5
+        for (int k0 = 0; k0 < D; k0 += 4) {
+          const int k = k0 + kq;
+          const bool in = k < D;
+          const float bv = in ? wp[min(k, D - 1) * H4] : 0.f;
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(in ? xa[min(k, D - 1)] : 0.f, bv, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(in ? xb[min(k, D - 1)] : 0.f, bv, acc1, 0, 0, 0);
+        }
+        const float b = a.b1[gc];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {  // C layout: column = lane & 15, row = 4 * (lane >> 4) + r
+          const int ta = t0 + 4 * kq + r, tb = ta + 16;
+          if (16 * ct + lj < G && ta < n_p) pre1[ta * G + gc] = acc0[r] + b;
+          if (16 * ct + lj < G && tb < n_p) pre1[tb * G + gc] = acc1[r] + b;
+        }
+      }
+    }
+  }
+  c = 0.f;
+  if (unit_thread) hbuf[tid] = 0.f;
+  {
+    float w[HC > 0 ? HC : 1];
+    const int off = dir * H * H4 + row;
+    __syncthreads();  // (the weights behind it: in front they would be live, and spilled, under the projections above)
+    col_load<HC>(w, a.Whh1t, off, H4);
+    for (int s = 0; s < n_p; ++s) {
+      const float v = col_dot<HC>(w, a.Whh1t, off, H4, hbuf + dir * H, H, pre1[(dir ? n_p - 1 - s : s) * G + g]);
+      if (gate_thread) gates[g] = activate(v, enc_tanh);
+      __syncthreads();
+      encoder_cell(s, false);
+      __syncthreads();
+    }
+  }
+  // ---- decoder: (h, c) = the last layer's final forward | backward states (DNN_tools.py:49-55) ----
+  {
+    // step 0: its input is the last history row of the phase (DNN_tools.py:224); later steps: its own previous output,
+    // folded into the recurrent matrix
+    float w[HC > 0 ? 2 * HC : 1];
+    col_load<2 * HC>(w, a.Wdhht, g, G);
+    float v0 = a.bd[g];
+    for (int z = 0; z < a.S2; ++z) v0 += a.P2[((int64_t)z * a.n_s + i) * a.ld2 + g];
+    const float bc = a.bcomb[g];
+    auto decoder_cell = [&](int j) __attribute__((always_inline)) {
+      __syncthreads();
+      if (unit_thread) {
+        c = gates[D + tid] * c + gates[tid] * gates[2 * D + tid];
+        const float hv = gates[3 * D + tid] * tanhf(c);
+        hbuf[tid] = hv;
+        a.Hs[((int64_t)j * a.n_s + i) * a.ldh + tid] = hv;
+      }
+      __syncthreads();
+    };
+    {
+      const float v = col_dot<2 * HC>(w, a.Wdhht, g, G, hbuf, D, v0);
+      if (gate_thread) gates[g] = activate(v, dec_tanh);
+      decoder_cell(0);
+    }
+    col_load<2 * HC>(w, a.Wcombt, g, G);
+    for (int j = 1; j < a.n_f; ++j) {
+      const float v = col_dot<2 * HC>(w, a.Wcombt, g, G, hbuf, D, bc);
+      if (gate_thread) gates[g] = activate(v, dec_tanh);
+      decoder_cell(j);
+    }
+  }
+}
+
+int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// How many ways to split K: the candidates are chunk-aligned slice lengths of at least 128; the best one fills whole rounds
+// of two workgroups per CU, and every further split costs a pass of partial sums and a pipeline start (0.01 of a round).
+void pick_splits(int M, int N, int K, int n_cu, int *splits, int *k_per_split) {
+  const int tiles = ((M + kBM - 1) / kBM) * ((N + kBN - 1) / kBN);
+  double best = -1e30;
+  *splits = 1;
+  *k_per_split = round_up(K, kKC);
+  for (int s = 1; s <= std::max(1, K / 128); ++s) {
+    const int kps = round_up((K + s - 1) / s, kKC), s_eff = (K + kps - 1) / kps;  // equal slices, the last one shorter
+    const int64_t wgs = (int64_t)tiles * s_eff, slots = 2 * (int64_t)n_cu, rounds = (wgs + slots - 1) / slots;
+    const double score = (double)wgs / (double)(rounds * slots) - 0.01 * s_eff;
+    if (score > best) {
+      best = score;
+      *splits = s_eff;
+      *k_per_split = kps;
+    }
+  }
+}
+
+}  // namespace
+
+struct Predictor {
+  int device = 0, n_cu = 256;
+  PredictorShape sh{};
+  int ldbI = 0, ldbD = 0, ldh = 0, S1 = 1, S2 = 1, kps1 = 0, kps2 = 0;
+  float *Wih0 = nullptr, *Wdih = nullptr, *Wfc = nullptr, *bfc = nullptr, *b0 = nullptr, *Whh0t = nullptr, *Wih1t = nullptr,
+        *Whh1t = nullptr, *b1 = nullptr, *Wdhht = nullptr, *bd = nullptr, *Wcombt = nullptr, *bcomb = nullptr, *P1 = nullptr,
+        *P2 = nullptr, *Hs = nullptr;
+  std::vector<void *> owned;
+};
+
+const PredictorShape &predictor_shape(const Predictor *p) { return p->sh; }
+int predictor_device(const Predictor *p) { return p->device; }
+
+void predictor_destroy(Predictor *p) {
+  if (!p) return;
+  for (void *q : p->owned) (void)hipFree(q);
+  delete p;
+}
+
+hipError_t predictor_create(int device, const PredictorShape &sh, const float *const *w, Predictor **out, std::string &err) {
+  const int I = sh.input_size, H = sh.hidden, D = 2 * H, G = 8 * H;
+  if (!w || !out || I < 1 || H < 1 || sh.n_past < 1 || sh.n_future < 1) {
+    err = "saa_predictor_create: bad shape";
+    return hipErrorInvalidValue;
+  }
+  if (sh.filter < 2) {  // n_s = 1: the reference's arange(i+n-n_p*n_s, i+n-1, n_s) then holds n_p - 1 rows
+    err = "saa_predictor_create: filter (n_s) must be at least 2";
+    return hipErrorInvalidValue;
+  }
+  if (G > 1024) {
+    err = "saa_predictor_create: hidden size above 128 is not supported (one thread per gate row)";
+    return hipErrorInvalidValue;
+  }
+  for (int j = 0; j < kPredictorWeights; ++j)
+    if (!w[j]) {
+      err = "saa_predictor_create: null weight tensor";
+      return hipErrorInvalidValue;
+    }
+  const size_t lds = (size_t)(G + D + (size_t)sh.n_past * D + (size_t)sh.n_past * G) * sizeof(float);
+  if (lds > 160 * 1024) {
+    err = "saa_predictor_create: n_past * hidden too large for the LDS of one workgroup";
+    return hipErrorInvalidValue;
+  }
+  hipError_t e = hipSetDevice(device);
+  if (e != hipSuccess) return e;
+  Predictor *p = new Predictor;
+  p->device = device;
+  p->sh = sh;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) p->n_cu = prop.multiProcessorCount;
+  p->ldbI = round_up(I, kKC);
+  p->ldbD = round_up(D, kKC);
+  p->ldh = round_up(D, kKC);
+  auto upload = [&](const std::vector<float> &h, float **dst) -> hipError_t {
+    void *q = nullptr;
+    hipError_t r = hipMalloc(&q, std::max<size_t>(h.size(), 1) * sizeof(float));
+    if (r != hipSuccess) return r;
+    p->owned.push_back(q);
+    *dst = static_cast<float *>(q);
+    return h.empty() ? hipSuccess : hipMemcpy(q, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice);
+  };
+#define PRED_TRY(expr)          \
+  do {                          \
+    hipError_t r_ = (expr);     \
+    if (r_ != hipSuccess) {     \
+      predictor_destroy(p);     \
+      return r_;                \
+    }                           \
+  } while (0)
+  // state_dict order: encoder l0, l0_reverse, l1, l1_reverse (weight_ih, weight_hh, bias_ih,
+  // bias_hh each), decoder lstm (4 tensors), decoder.fc.weight, decoder.fc.bias
+  const float *e_ih[2][2] = {{w[0], w[4]}, {w[8], w[12]}}, *e_hh[2][2] = {{w[1], w[5]}, {w[9], w[13]}},
+              *e_bi[2][2] = {{w[2], w[6]}, {w[10], w[14]}}, *e_bh[2][2] = {{w[3], w[7]}, {w[11], w[15]}};
+  const float *d_ih = w[16], *d_hh = w[17], *d_bi = w[18], *d_bh = w[19], *fc_w = w[20], *fc_b = w[21];
+  const int H4 = 4 * H;
+  {  // B of GEMM 1: rows = gate rows of layer 0, forward then backward; zero-padded to ldbI
+    std::vector<float> B((size_t)G * p->ldbI, 0.f), b(G), t((size_t)2 * H * H4);
+    for (int d = 0; d < 2; ++d)
+      for (int r = 0; r < H4; ++r) {
+        std::copy(e_ih[0][d] + (size_t)r * I, e_ih[0][d] + (size_t)(r + 1) * I, B.begin() + (size_t)(d * H4 + r) * p->ldbI);
+        b[d * H4 + r] = (float)((double)e_bi[0][d][r] + (double)e_bh[0][d][r]);
+        for (int k = 0; k < H; ++k) t[((size_t)d * H + k) * H4 + r] = e_hh[0][d][(size_t)r * H + k];
+      }
+    PRED_TRY(upload(B, &p->Wih0));
+    PRED_TRY(upload(b, &p->b0));
+    PRED_TRY(upload(t, &p->Whh0t));
+  }
+  {  // layer 1
+    std::vector<float> ti((size_t)2 * D * H4), th((size_t)2 * H * H4), b(G);
+    for (int d = 0; d < 2; ++d)
+      for (int r = 0; r < H4; ++r) {
+        b[d * H4 + r] = (float)((double)e_bi[1][d][r] + (double)e_bh[1][d][r]);
+        for (int k = 0; k < D; ++k) ti[((size_t)d * D + k) * H4 + r] = e_ih[1][d][(size_t)r * D + k];
+        for (int k = 0; k < H; ++k) th[((size_t)d * H + k) * H4 + r] = e_hh[1][d][(size_t)r * H + k];
+      }
+    PRED_TRY(upload(ti, &p->Wih1t));
+    PRED_TRY(upload(th, &p->Whh1t));
+    PRED_TRY(upload(b, &p->b1));
+  }
+  {  // decoder: first step as it stands, later steps with the output layer folded in (fp64, one rounding to fp32)
+    std::vector<float> B((size_t)G * p->ldbI, 0.f), th((size_t)D * G), tc((size_t)D * G), b(G), bc(G);
+    std::vector<double> accv(D);
+    for (int r = 0; r < G; ++r) {
+      std::copy(d_ih + (size_t)r * I, d_ih + (size_t)(r + 1) * I, B.begin() + (size_t)r * p->ldbI);
+      std::fill(accv.begin(), accv.end(), 0.0);
+      double accb = 0.0;
+      for (int q = 0; q < I; ++q) {
+        const double wq = d_ih[(size_t)r * I + q];
+        const float *f = fc_w + (size_t)q * D;
+        for (int k = 0; k < D; ++k) accv[k] += wq * (double)f[k];
+        accb += wq * (double)fc_b[q];
+      }
+      b[r] = (float)((double)d_bi[r] + (double)d_bh[r]);
+      bc[r] = (float)(accb + (double)d_bi[r] + (double)d_bh[r]);
+      for (int k = 0; k < D; ++k) {
+        th[(size_t)k * G + r] = d_hh[(size_t)r * D + k];
+        tc[(size_t)k * G + r] = (float)(accv[k] + (double)d_hh[(size_t)r * D + k]);
+      }
+    }
+    PRED_TRY(upload(B, &p->Wdih));
+    PRED_TRY(upload(th, &p->Wdhht));
+    PRED_TRY(upload(tc, &p->Wcombt));
+    PRED_TRY(upload(b, &p->bd));
+    PRED_TRY(upload(bc, &p->bcomb));
+  }
+  {  // output layer: B of GEMM 4 (N = I rows of 2H), zero-padded to ldbD
+    std::vector<float> B((size_t)I * p->ldbD, 0.f), b(fc_b, fc_b + I);
+    for (int q = 0; q < I; ++q) std::copy(fc_w + (size_t)q * D, fc_w + (size_t)(q + 1) * D, B.begin() + (size_t)q * p->ldbD);
+    PRED_TRY(upload(B, &p->Wfc));
+    PRED_TRY(upload(b, &p->bfc));
+  }
+  pick_splits(sh.n_past * sh.filter, G, I, p->n_cu, &p->S1, &p->kps1);
+  pick_splits(sh.filter, G, I, p->n_cu, &p->S2, &p->kps2);
+  PRED_TRY(upload(std::vector<float>((size_t)p->S1 * sh.n_past * sh.filter * G, 0.f), &p->P1));
+  PRED_TRY(upload(std::vector<float>((size_t)p->S2 * sh.filter * G, 0.f), &p->P2));
+  PRED_TRY(upload(std::vector<float>((size_t)sh.n_future * sh.filter * p->ldh, 0.f), &p->Hs));
+  PRED_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&lstm_recurrence_kernel<0>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  PRED_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&lstm_recurrence_kernel<50>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  PRED_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_nt_kernel<true, false>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGemmLds));
+  PRED_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_nt_kernel<false, true>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGemmLds));
+#undef PRED_TRY
+  *out = p;
+  return hipSuccess;
+}
+
+hipError_t predictor_predict(Predictor *p, const double *hist, int64_t ld_hist, int64_t n, double scale_max, double scale_min,
+                             double *table, int64_t ld_table, hipStream_t st) {
+  const PredictorShape &sh = p->sh;
+  const int I = sh.input_size, H = sh.hidden, D = 2 * H, G = 8 * H, M1 = sh.n_past * sh.filter;
+  GemmArgs g{};
+  g.lda = ld_hist;
+  g.ldb = p->ldbI;
+  g.N = G;
+  g.K = I;
+  g.smax = scale_max;
+  g.sden = -scale_min + scale_max;  // DNN_tools.py:274
+  g.ldc = G;
+  // 1. encoder layer 0, input projection of every row of the window
+  g.A = hist + (n - M1) * ld_hist;
+  g.B = p->Wih0;
+  g.M = M1;
+  g.k_per_split = p->kps1;
+  g.Cpart = p->P1;
+  hipLaunchKernelGGL((gemm_nt_kernel<true, false>), dim3((M1 + kBM - 1) / kBM, (G + kBN - 1) / kBN, p->S1), dim3(kGemmThreads),
+                     kGemmLds, st, g);
+  // 2. decoder, first step: the last history row of each phase, rows [n - n_s, n)
+  g.A = hist + (n - sh.filter) * ld_hist;
+  g.B = p->Wdih;
+  g.M = sh.filter;
+  g.k_per_split = p->kps2;
+  g.Cpart = p->P2;
+  hipLaunchKernelGGL((gemm_nt_kernel<true, false>), dim3((sh.filter + kBM - 1) / kBM, (G + kBN - 1) / kBN, p->S2),
+                     dim3(kGemmThreads), kGemmLds, st, g);
+  // 3. recurrences
+  LstmArgs a{};
+  a.H = H;
+  a.n_p = sh.n_past;
+  a.n_f = sh.n_future;
+  a.n_s = sh.filter;
+  a.S1 = p->S1;
+  a.S2 = p->S2;
+  a.P1 = p->P1;
+  a.ld1 = G;
+  a.P2 = p->P2;
+  a.ld2 = G;
+  a.b0 = p->b0;
+  a.Whh0t = p->Whh0t;
+  a.Wih1t = p->Wih1t;
+  a.Whh1t = p->Whh1t;
+  a.b1 = p->b1;
+  a.Wdhht = p->Wdhht;
+  a.bd = p->bd;
+  a.Wcombt = p->Wcombt;
+  a.bcomb = p->bcomb;
+  a.Hs = p->Hs;
+  a.ldh = p->ldh;
+  const size_t lds = (size_t)(G + D + (size_t)sh.n_past * D + (size_t)sh.n_past * G) * sizeof(float);
+  if (H == 50)  // the reference's hidden size (Online_predictor.py:139: nH-50): weights in registers
+    hipLaunchKernelGGL(lstm_recurrence_kernel<50>, dim3(sh.filter), dim3(lstm_threads(50)), lds, st, a);
+  else
+    hipLaunchKernelGGL(lstm_recurrence_kernel<0>, dim3(sh.filter), dim3(round_up(G, 64)), lds, st, a);
+  // 4. outputs of all steps and phases, scaled back (fp32) and widened into the table
+  GemmArgs o{};
+  o.A = p->Hs;
+  o.lda = p->ldh;
+  o.B = p->Wfc;
+  o.ldb = p->ldbD;
+  o.M = sh.n_future * sh.filter;
+  o.N = I;
+  o.K = D;
+  o.k_per_split = p->ldbD;
+  o.bias = p->bfc;
+  o.range32 = (float)(scale_max - scale_min);  // DNN_tools.py:278: fp32 tensor times Python scalar, plus Python scalar
+  o.max32 = (float)scale_max;
+  o.table = table;
+  o.ldt = ld_table;
+  hipLaunchKernelGGL((gemm_nt_kernel<false, true>), dim3((o.M + kBM - 1) / kBM, (I + kBN - 1) / kBN, 1), dim3(kGemmThreads), kGemmLds,
+                     st, o);
+  return hipGetLastError();
+}
+
+}  // namespace saa

@@ -150,13 +150,83 @@ def scaling_constants(displacement_shared, filter_size, n_past, n_future, cut_of
     return data32.max().item(), data32.min().item()
 
 
+#: the reference's state_dict keys in its own order (``Model_training.py:179-180`` saves them) - the
+#: order ``saa_predictor_create`` takes the tensors in
+STATE_KEYS = tuple(
+    [f"encoder.lstm_encoder.{name}_l{layer}{sfx}" for layer in (0, 1) for sfx in ("", "_reverse")
+     for name in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
+    + [f"decoder.lstm_decoder.{name}_l0" for name in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
+    + ["decoder.fc.weight", "decoder.fc.bias"])
+
+
+class NativePredictor:
+    """The model on the HIP library's own kernels (``csrc/saa_predictor.hip``, C ABI ``saa_predictor_*``): the window's
+    3000 history rows go through ONE f32 matrix-core GEMM (the fp64 scaling to [-1, 0] fused into its loads), the
+    recurrences run one workgroup per phase with the decoder's output layer folded into its recurrent matrix, and a second
+    GEMM scales back and writes the fp64 table - four launches where the PyTorch path takes ~600 (4.7 ms -> 0.5 ms per
+    window at 9126 inputs).  fp32 like the reference; another summation order than ATen's (round-off level differences)."""
+
+    def __init__(self, model, n_past, n_future, filter_size, device_index=0):
+        import ctypes as C
+
+        from . import _lib
+
+        sd = model.state_dict()
+        missing = [k for k in STATE_KEYS if k not in sd]
+        if missing:
+            raise ValueError(f"not the reference's encoder-decoder: state_dict lacks {missing[:3]}")
+        self._lib, self._h = _lib.load(), C.c_void_p()
+        self.input_size, hidden = int(sd[STATE_KEYS[0]].shape[1]), int(sd[STATE_KEYS[1]].shape[1])
+        want = {"encoder.lstm_encoder.weight_ih_l1": (4 * hidden, 2 * hidden),
+                "decoder.lstm_decoder.weight_ih_l0": (8 * hidden, self.input_size),
+                "decoder.lstm_decoder.weight_hh_l0": (8 * hidden, 2 * hidden),
+                "decoder.fc.weight": (self.input_size, 2 * hidden)}
+        for k, shape in want.items():
+            if tuple(sd[k].shape) != shape:
+                raise ValueError(f"{k} has shape {tuple(sd[k].shape)}, the reference's architecture needs {shape}")
+        host = [sd[k].detach().to("cpu", torch.float32).contiguous() for k in STATE_KEYS]
+        ptrs = (C.POINTER(C.c_float) * len(host))(*[C.cast(t.data_ptr(), C.POINTER(C.c_float)) for t in host])
+        self.n_p, self.n_f, self.n_s, self.device_index = int(n_past), int(n_future), int(filter_size), int(device_index)
+        _lib.check(self._lib.saa_predictor_create(self.device_index, self.input_size, hidden, self.n_p, self.n_f, self.n_s,
+                                                  ptrs, len(host), C.byref(self._h)))
+
+    def predict(self, n, hist, scale_max, scale_min, table=None):
+        """``hist``: fp64 CUDA tensor ``(rows, input_size)`` (unit stride along the inputs); returns the fp64 table
+        ``(n_s*n_f, input_size)`` on the same device, enqueued on torch's current stream."""
+        from . import _lib
+
+        if not (hist.is_cuda and hist.dtype == torch.float64 and hist.dim() == 2 and hist.stride(1) == 1
+                and hist.shape[1] == self.input_size and hist.device.index == self.device_index):
+            raise ValueError("history must be a float64 (rows, input_size) tensor on the predictor's GPU")
+        if table is None:
+            table = torch.empty((self.n_s * self.n_f, self.input_size), dtype=torch.float64, device=hist.device)
+        stream = torch.cuda.current_stream(hist.device).cuda_stream
+        _lib.check(self._lib.saa_predictor_predict(self._h, hist.data_ptr(), hist.shape[0], hist.stride(0), int(n),
+                                                   float(scale_max), float(scale_min), table.data_ptr(), table.stride(0),
+                                                   stream))
+        return table
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.saa_predictor_destroy(self._h)
+            self._h.value = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class DevicePredictor:
     """Callable for :func:`distributed.run_hybrid`: keeps model and scaling on the solver's device.
 
-    One call is ~600 launches of microsecond kernels (7 ms from Python for 1.5 ms of GPU work, against ~33 ms of time
-    stepping per window).  On a GPU the call is therefore captured as a HIP graph after ``warmup`` eager calls and
-    replayed: the window position ``n`` lives in a device scalar, the history tensor and the output table are static
-    (``run_hybrid`` allocates the history once and consumes the table before the next call)."""
+    On a GPU the window's table comes from :class:`NativePredictor` (the library's own kernels; four launches).
+    ``SAA_PREDICT_NATIVE=0`` selects the PyTorch-ROCm path instead (MIOpen / rocBLAS): one call is ~600 launches of
+    microsecond kernels (7 ms from Python for 1.5 ms of GPU work, against ~33 ms of time stepping per window), so it is
+    captured as a HIP graph after ``warmup`` eager calls and replayed: the window position ``n`` lives in a device scalar,
+    the history tensor and the output table are static (``run_hybrid`` allocates the history once and consumes the table
+    before the next call).  On the CPU (the drop-in's ``device='cpu'``) the call is the eager batched PyTorch one."""
 
     def __init__(self, model, n_past, n_future, filter_size, scale_max, scale_min, warmup=2):
         import os
@@ -166,6 +236,8 @@ class DevicePredictor:
         self.scale_max, self.scale_min = float(scale_max), float(scale_min)
         self._graph, self._key, self._calls, self._warmup = None, None, 0, warmup
         self._use_graph = os.environ.get("SAA_PREDICT_GRAPH", "1") != "0"
+        self._use_native = os.environ.get("SAA_PREDICT_NATIVE", "1") != "0" and filter_size >= 2
+        self._native, self._native_table = None, None
 
     def _eager(self, n, hist):
         return predict_table(self.model, n, self.n_p, self.n_f, self.n_s, hist, self.scale_max, self.scale_min)
@@ -198,7 +270,17 @@ class DevicePredictor:
         self._graph, self._key = graph, (hist.data_ptr(), tuple(hist.shape))
         return True
 
+    @property
+    def backend(self):
+        return "native HIP" if self._use_native else ("PyTorch-ROCm, HIP graph" if self._use_graph else "PyTorch-ROCm")
+
     def __call__(self, n, hist):
+        if self._use_native and hist.is_cuda:
+            if self._native is None or self._native.device_index != hist.device.index:
+                self._native = NativePredictor(self.model, self.n_p, self.n_f, self.n_s, hist.device.index)
+                self._native_table = torch.empty((self.n_s * self.n_f, hist.shape[1]), dtype=torch.float64,
+                                                 device=hist.device)
+            return self._native.predict(n, hist, self.scale_max, self.scale_min, self._native_table)
         if not (self._use_graph and hist.is_cuda):
             return self._eager(n, hist)
         if self._graph is not None and self._key != (hist.data_ptr(), tuple(hist.shape)):

@@ -1,0 +1,114 @@
+"""The library's own predictor kernels (csrc/saa_predictor.hip, C ABI saa_predictor_*) against the oracle's sequential
+batch-1 restatement of DNN_prediction.py:38-55, the reference-generated fixture and the PyTorch-ROCm path.
+
+fp32 model: the kernels add in another order than ATen (matrix-core k-order, split-K partial sums, the decoder's output
+layer folded into its recurrent matrix in fp64), so the bar is fp32 round-off carried through 2 x n_p + n_f recurrent
+steps: 2e-5 of the table's range (the PyTorch GPU path is held to 1e-4 against the same fixture)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from synchronization_avoiding_algorithms_amd import _lib
+from synchronization_avoiding_algorithms_amd import predictor as pr
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-5
+
+
+def _oracle_table(model, n, n_p, n_f, n_s, hist, smax, smin):
+    from oracle import lstm_oracle as lo
+
+    cpu = lo.load_model(model.input_size, model.hidden_size, {k: v.cpu() for k, v in model.state_dict().items()})
+    return lo.predictor_table(n, cpu, n_p, n_f, n_s, model.input_size, hist, smax, smin)
+
+
+def _range(a):
+    return float(np.abs(a).max())
+
+
+def test_fixture_of_the_reference(tmp_path):
+    """24 inputs, H = 50, n_p = n_f = 20: the table the reference's own encoder_decoder_predictor wrote."""
+    g = load_golden("predictor_table.npz")
+    path = tmp_path / "model.pth"
+    torch.save({k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("w::")}, path)
+    model = pr.call_model("cuda", int(g["n_s"]), int(g["input_size"]), int(g["hidden_size"]), str(path))
+    nat = pr.NativePredictor(model, int(g["n_p"]), int(g["n_f"]), int(g["n_s"]))
+    smax, smin = (float(v) for v in g["scale"])
+    hist = torch.from_numpy(g["d_sol"]).cuda()
+    table = nat.predict(int(g["n"]), hist, smax, smin).cpu().numpy()
+    assert table.shape == g["NF"].shape and table.dtype == np.float64
+    assert np.abs(table - g["NF"]).max() <= TOL * _range(g["NF"])
+    assert np.array_equal(table, table.astype(np.float32).astype(np.float64))  # fp32 values widened (:54)
+    # DevicePredictor takes this path by default on a GPU
+    dev = pr.DevicePredictor(model, int(g["n_p"]), int(g["n_f"]), int(g["n_s"]), smax, smin)
+    assert dev.backend == "native HIP"
+    assert np.array_equal(dev(int(g["n"]), hist).cpu().numpy(), table)
+
+
+@pytest.mark.parametrize("shape", [
+    dict(I=3, H=5, n_p=3, n_f=2, n_s=2),          # one shared node, the smallest window the reference's indexing allows
+    dict(I=27, H=8, n_p=4, n_f=3, n_s=10),        # odd input count: no 16-byte aligned history rows
+    dict(I=24, H=50, n_p=20, n_f=20, n_s=150),    # beam_coarse at the reference's settings
+    dict(I=1031, H=16, n_p=5, n_f=6, n_s=70),     # several K chunks and splits, ragged last chunk, 350 rows (5.5 row tiles)
+    dict(I=450, H=128, n_p=3, n_f=4, n_s=3),      # the widest model the kernel takes (1024 gate rows)
+])
+def test_against_the_sequential_oracle(shape):
+    I, H, n_p, n_f, n_s = (shape[k] for k in ("I", "H", "n_p", "n_f", "n_s"))
+    torch.manual_seed(I + H)
+    model = pr.LSTM_encoder_decoder(I, H).cuda().eval()
+    rng = np.random.default_rng(I)
+    rows = n_p * n_s + 37
+    hist = np.cumsum(rng.normal(0, 1e-4, size=(rows, I)), axis=0)
+    smax, smin = float(hist.max()) * 1.1, float(hist.min()) * 1.1
+    nat = pr.NativePredictor(model, n_p, n_f, n_s)
+    dh = torch.from_numpy(hist).cuda()
+    for n in (n_p * n_s, rows - 5, rows):
+        want = _oracle_table(model, n, n_p, n_f, n_s, hist, smax, smin)
+        got = nat.predict(n, dh, smax, smin).cpu().numpy()
+        assert np.abs(got - want).max() <= TOL * _range(want), (shape, n, np.abs(got - want).max() / _range(want))
+    # only rows [n - n_p*n_s, n) are read: everything else may hold anything
+    poisoned = dh.clone()
+    n = rows - 5
+    poisoned[: n - n_p * n_s] = float("nan")
+    poisoned[n:] = float("nan")
+    assert torch.equal(nat.predict(n, poisoned, smax, smin), nat.predict(n, dh, smax, smin))
+
+
+def test_config4_shape_against_pytorch_rocm():
+    """9126 inputs (the interior slab of the 8-way partition of the 8.2M-tet beam), H = 50, 20/20/150: against the
+    PyTorch-ROCm evaluation of the same weights (MIOpen LSTM, rocBLAS GEMMs) - two fp32 evaluations in different orders."""
+    I, H, n_p, n_f, n_s = 9126, 50, 20, 20, 150
+    torch.manual_seed(1)
+    model = pr.LSTM_encoder_decoder(I, H).cuda().eval()
+    gen = torch.Generator(device="cuda").manual_seed(2)
+    hist = torch.cumsum(torch.randn(n_p * n_s + 100, I, generator=gen, device="cuda", dtype=torch.float64) * 1e-4, 0)
+    smax, smin = float(hist.max()) * 1.05, float(hist.min()) * 1.05
+    nat = pr.NativePredictor(model, n_p, n_f, n_s)
+    for n in (n_p * n_s, n_p * n_s + 100):
+        with torch.no_grad():
+            want = pr.predict_table(model, n, n_p, n_f, n_s, hist, smax, smin)
+        got = nat.predict(n, hist, smax, smin)
+        err = float((got - want).abs().max() / want.abs().max())
+        assert err <= TOL, err
+        assert torch.equal(got, nat.predict(n, hist, smax, smin))  # deterministic: fixed summation orders
+
+
+def test_arguments_are_checked():
+    torch.manual_seed(0)
+    model = pr.LSTM_encoder_decoder(6, 4).cuda().eval()
+    with pytest.raises(_lib.SaaError, match="at least 2"):
+        pr.NativePredictor(model, 4, 3, 1)
+    nat = pr.NativePredictor(model, 4, 3, 5)
+    hist = torch.zeros(30, 6, dtype=torch.float64, device="cuda")
+    with pytest.raises(_lib.SaaError, match="inside the history"):
+        nat.predict(19, hist, 1.0, -1.0)
+    with pytest.raises(_lib.SaaError, match="inside the history"):
+        nat.predict(31, hist, 1.0, -1.0)
+    with pytest.raises(_lib.SaaError, match="scale_max == scale_min"):
+        nat.predict(25, hist, 1.0, 1.0)
+    with pytest.raises(ValueError, match="float64"):
+        nat.predict(25, hist.float(), 1.0, -1.0)
+    # n_s = 1 (the reference's windows then hold n_p - 1 rows): DevicePredictor keeps the PyTorch path
+    assert pr.DevicePredictor(model, 4, 3, 1, 1.0, -1.0).backend != "native HIP"
+    nat.close()
