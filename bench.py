@@ -416,8 +416,15 @@ def sync_avoiding_leg(part, args, rank, world, ne_total, fence, train_seconds):
     errs, elapsed, i = [], 0.0, start
     with torch.no_grad():
         part.step_synced(start, hist, 0)
-        for _ in range(3):  # untimed: the predictor captures its HIP graph on the third call
+        for _ in range(3):  # untimed: the PyTorch-ROCm route (SAA_PREDICT_NATIVE=0) captures its HIP graph on the third call
             predictor(start, hist)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        ev[0].record()
+        for _ in range(5):
+            predictor(start, hist)
+        ev[1].record()
+        torch.cuda.synchronize()
+        predictor_ms = ev[0].elapsed_time(ev[1]) / 5
         for w in range(windows):
             fence()
             t0 = time.perf_counter()
@@ -442,6 +449,8 @@ def sync_avoiding_leg(part, args, rank, world, ne_total, fence, train_seconds):
             "ms_per_step": 1e3 * elapsed / (windows * win), "steps": windows * win, "windows": windows,
             "n_past": n_p, "n_future": n_f, "filter_size": n_s, "input_size_rank0": width,
             "synchronised_steps_before": start,
+            "predictor": {"backend": predictor.backend, "ms_per_window_rank0": predictor_ms,
+                          "note": "one call = the table of a whole window (all filter_size phases); inside the timed region"},
             "rel_l2_vs_synchronised": errs, "state_finite": bool(finite.item()),
             "training": {"truth_steps": n_truth, "windows": int(groups), "epochs": len(tl),
                          "epochs_min_over_ranks": int(ep.item()), "schedule": schedule, "seconds": train_s,

@@ -32,7 +32,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // zero-padded to a multiple of 32.  Workgroup: 256 threads = 4 waves, 64 rows x 208 columns of C; a wave holds 16 rows x
 // 13 tiles of 16 columns (52 accumulator registers).  TWO workgroups per CU, i.e. two waves per SIMD that are NOT in
 // lock-step: while one stores its next chunk and waits at its barrier the other multiplies (eight waves of one workgroup
-// reach every barrier together and the matrix cores idle: 55 TFLOP/s against 45 with the compiler's own schedule).
+// reach every barrier together and the matrix cores idle: 55 TFLOP/s against 45 with the compiler's own schedule; three
+// workgroups per CU leave 168 registers per lane, which spills inside the chunk loop: 25 TFLOP/s).
+// Measured on the 3000 x 9126 history against 400 gate rows: 283 us = 77 TFLOP/s, 0.49 of the 157 TFLOP/s f32 matrix peak;
+// in-kernel stamps (tools/gemm_stamps.hip) put the matrix pipe of a SIMD at 75 % busy over a workgroup's life.
 // What a wave needs of a chunk - two b128 reads of A, twenty-six of B - is requested in one go and the MFMAs run tile
 // after tile on independent accumulators; fences keep that order in the binary (left alone the compiler reads one
 // fragment, waits, and issues four dependent MFMAs, thirteen times per group).
@@ -53,7 +56,7 @@ struct GemmArgs {
   const float *B;
   int64_t ldb;
   int M, N, K, k_per_split;
-  double smax, sden;  // A_F64: a = (float)((x - smax) / sden)
+  double smax, sden, srcp;  // A_F64: a = (float)((x - smax) / sden); srcp = 1 / sden, correctly rounded (host division)
   float *Cpart;       // !TABLE: [splits][M][ldc]
   int64_t ldc;
   const float *bias;  // TABLE: table[m][n] = (double)((acc + bias[n]) * range32 + max32), two fp32 roundings
@@ -82,28 +85,42 @@ __global__ void __launch_bounds__(kGemmThreads) __attribute__((amdgpu_waves_per_
   // called from two places and therefore not inlined, leaves them in scratch memory - one load at a time, each waited for)
   AT areg[kAq];
   f32x4 breg[kBq];
-  // (unconditional loads at clamped indices; what lies outside is zeroed when it is stored)
+  // (unconditional loads at clamped indices; what lies outside is zeroed when it is stored.  Addresses = a wave-uniform
+  // base + a 32-bit lane offset whose row part is formed once: with 64-bit index arithmetic per load and chunk the
+  // requests alone took 1400 cycles of a chunk's 9500.  The host checks that the offsets fit 31 bits.)
+  const char *abase = static_cast<const char *>(g.A) + (int64_t)m0 * g.lda * (int64_t)sizeof(AT);
+  const char *bbase = reinterpret_cast<const char *>(g.B) + (int64_t)n0 * g.ldb * (int64_t)sizeof(float);
+  uint32_t arow[kAq], brow[kBq];
+#pragma unroll
+  for (int q = 0; q < kAq; ++q)
+    arow[q] = (uint32_t)min((tid + kGemmThreads * q) >> 5, g.M - 1 - m0) * (uint32_t)g.lda * (uint32_t)sizeof(AT);
+#pragma unroll
+  for (int q = 0; q < kBq; ++q)
+    brow[q] = ((uint32_t)min(min((tid + kGemmThreads * q) >> 3, kBN - 1), g.N - 1 - n0) * (uint32_t)g.ldb + 4u * (tid & 7)) *
+              (uint32_t)sizeof(float);
   auto load_chunk = [&](int k0) __attribute__((always_inline)) {
+    const uint32_t ka = (uint32_t)min(k0 + (tid & 31), g.K - 1) * (uint32_t)sizeof(AT);
 #pragma unroll
-    for (int q = 0; q < kAq; ++q) {
-      const int e = tid + kGemmThreads * q, row = e >> 5, kk = e & 31;
-      const int gm = min(m0 + row, g.M - 1), gk = min(k0 + kk, g.K - 1);
-      areg[q] = static_cast<const AT *>(g.A)[(int64_t)gm * g.lda + gk];
-    }
+    for (int q = 0; q < kAq; ++q) areg[q] = *reinterpret_cast<const AT *>(abase + (arow[q] + ka));
+    const char *bk = bbase + (int64_t)k0 * (int64_t)sizeof(float);
 #pragma unroll
-    for (int q = 0; q < kBq; ++q) {
-      const int p = tid + kGemmThreads * q, r = min(p >> 3, kBN - 1), c4 = p & 7;
-      const int gn = min(n0 + r, g.N - 1);
-      breg[q] = *reinterpret_cast<const f32x4 *>(g.B + (int64_t)gn * g.ldb + k0 + 4 * c4);
-    }
+    for (int q = 0; q < kBq; ++q) breg[q] = *reinterpret_cast<const f32x4 *>(bk + brow[q]);
   };
   auto store_chunk = [&](int k0) __attribute__((always_inline)) {
 #pragma unroll
     for (int q = 0; q < kAq; ++q) {
       const int e = tid + kGemmThreads * q, row = e >> 5, kk = e & 31;
       float v;
-      if (A_F64) v = (float)(((double)areg[q] - g.smax) / g.sden);  // DNN_tools.py:272-275 in fp64, then .float()
-      else v = (float)areg[q];
+      if (A_F64) {
+        // (x - max) / (max - min) in fp64, then .float() (DNN_tools.py:272-275, DNN_prediction.py:48-49).  The quotient
+        // through the correctly rounded reciprocal and one residual correction (Markstein: q within an ulp, r = n - q d
+        // exact in an FMA, q + r / d rounds to the IEEE quotient) - four instructions where the division sequence has
+        // thirteen dependent ones, eight times per thread and chunk.
+        const double num = (double)areg[q] - g.smax, q0 = num * g.srcp;
+        v = (float)fma(fma(-q0, g.sden, num), g.srcp, q0);
+      } else {
+        v = (float)areg[q];
+      }
       As[row * kLd + kk] = (m0 + row < g.M && k0 + kk < kend) ? v : 0.f;
     }
 #pragma unroll
@@ -273,12 +290,26 @@ __global__ void __launch_bounds__(lstm_threads(HC)) lstm_recurrence_kernel(LstmA
   //      fixed order - go to LDS first, all time steps at once (many loads in flight; a load inside the step loop is waited
   //      for in every step) ---------------------------------------------------
   if (unit_thread) hbuf[tid] = 0.f;
-  if (gate_thread) {
+  if (gate_thread) {  // (four time steps and four partial sums per round trip: one load per trip is 100 trips at S1 = 5)
     const float b = a.b0[g];
-    for (int t = 0; t < n_p; ++t) {
-      float v = b;
-      for (int z = 0; z < a.S1; ++z) v += a.P1[(z * M1 + (int64_t)t * a.n_s + i) * a.ld1 + g];
-      pre1[t * G + g] = v;
+    for (int t0 = 0; t0 < n_p; t0 += 4) {
+      float v0 = b, v1 = b, v2 = b, v3 = b;
+      const float *q0 = a.P1 + ((int64_t)min(t0, n_p - 1) * a.n_s + i) * a.ld1 + g,
+                  *q1 = a.P1 + ((int64_t)min(t0 + 1, n_p - 1) * a.n_s + i) * a.ld1 + g,
+                  *q2 = a.P1 + ((int64_t)min(t0 + 2, n_p - 1) * a.n_s + i) * a.ld1 + g,
+                  *q3 = a.P1 + ((int64_t)min(t0 + 3, n_p - 1) * a.n_s + i) * a.ld1 + g;
+      const int64_t zs = M1 * a.ld1;
+#pragma unroll 4
+      for (int z = 0; z < a.S1; ++z) {
+        v0 += q0[z * zs];
+        v1 += q1[z * zs];
+        v2 += q2[z * zs];
+        v3 += q3[z * zs];
+      }
+      pre1[t0 * G + g] = v0;
+      if (t0 + 1 < n_p) pre1[(t0 + 1) * G + g] = v1;
+      if (t0 + 2 < n_p) pre1[(t0 + 2) * G + g] = v2;
+      if (t0 + 3 < n_p) pre1[(t0 + 3) * G + g] = v3;
     }
   }
   {
@@ -345,6 +376,7 @@ __global__ void __launch_bounds__(lstm_threads(HC)) lstm_recurrence_kernel(LstmA
     float w[HC > 0 ? 2 * HC : 1];
     col_load<2 * HC>(w, a.Wdhht, g, G);
     float v0 = a.bd[g];
+#pragma unroll 8
     for (int z = 0; z < a.S2; ++z) v0 += a.P2[((int64_t)z * a.n_s + i) * a.ld2 + g];
     const float bc = a.bcomb[g];
     auto decoder_cell = [&](int j) __attribute__((always_inline)) {
@@ -421,6 +453,10 @@ hipError_t predictor_create(int device, const PredictorShape &sh, const float *c
   }
   if (sh.filter < 2) {  // n_s = 1: the reference's arange(i+n-n_p*n_s, i+n-1, n_s) then holds n_p - 1 rows
     err = "saa_predictor_create: filter (n_s) must be at least 2";
+    return hipErrorInvalidValue;
+  }
+  if ((int64_t)sh.n_past * sh.filter * I * 8 >= (1ll << 31) || (int64_t)std::max(I, G) * (round_up(std::max(I, D), kKC)) * 4 >= (1ll << 31)) {
+    err = "saa_predictor_create: window too large (n_past * filter * input_size * 8 bytes must stay below 2 GiB)";
     return hipErrorInvalidValue;
   }
   if (G > 1024) {
@@ -554,6 +590,7 @@ hipError_t predictor_predict(Predictor *p, const double *hist, int64_t ld_hist, 
   g.K = I;
   g.smax = scale_max;
   g.sden = -scale_min + scale_max;  // DNN_tools.py:274
+  g.srcp = 1.0 / g.sden;
   g.ldc = G;
   // 1. encoder layer 0, input projection of every row of the window
   g.A = hist + (n - M1) * ld_hist;

@@ -75,9 +75,25 @@ def test_against_the_sequential_oracle(shape):
     assert torch.equal(nat.predict(n, poisoned, smax, smin), nat.predict(n, dh, smax, smin))
 
 
-def test_config4_shape_against_pytorch_rocm():
-    """9126 inputs (the interior slab of the 8-way partition of the 8.2M-tet beam), H = 50, 20/20/150: against the
-    PyTorch-ROCm evaluation of the same weights (MIOpen LSTM, rocBLAS GEMMs) - two fp32 evaluations in different orders."""
+def _fp64_table(model, n, n_p, n_f, n_s, hist, smax, smin):
+    """The same model evaluated in fp64 on the GPU (weights widened, the scaled history not rounded to fp32)."""
+    import copy
+
+    m64 = copy.deepcopy(model).double()
+    past, fut = pr._phase_indices(n, n_p, n_f, n_s)
+    with torch.no_grad():
+        X = pr.scale_forward(hist[torch.as_tensor(np.stack(past), device=hist.device)], smax, smin)
+        Y = pr.scale_it_back(pr.model_predict(hist.device, m64, X, n_f), smax, smin)
+    table = torch.zeros((n_s * n_f, hist.shape[1]), dtype=torch.float64, device=hist.device)
+    table[torch.as_tensor(np.stack(fut), device=hist.device).reshape(-1)] = Y.reshape(-1, hist.shape[1])
+    return table
+
+
+def test_config4_shape_against_the_fp64_evaluation_and_pytorch_rocm():
+    """9126 inputs (the interior slab of the 8-way partition of the 8.2M-tet beam), H = 50, 20/20/150.  Two fp32
+    evaluations that add 9126 terms in different orders - these kernels and PyTorch-ROCm (MIOpen LSTM, rocBLAS GEMMs) -
+    differ by 4e-5 of the range; measured against the SAME weights evaluated in fp64 the kernels are at 7e-6 and PyTorch's
+    fp32 path at 4e-5 (tools/predictor_point.py), so the bar is set against fp64: 2e-5, and not worse than PyTorch's."""
     I, H, n_p, n_f, n_s = 9126, 50, 20, 20, 150
     torch.manual_seed(1)
     model = pr.LSTM_encoder_decoder(I, H).cuda().eval()
@@ -86,11 +102,14 @@ def test_config4_shape_against_pytorch_rocm():
     smax, smin = float(hist.max()) * 1.05, float(hist.min()) * 1.05
     nat = pr.NativePredictor(model, n_p, n_f, n_s)
     for n in (n_p * n_s, n_p * n_s + 100):
+        ref = _fp64_table(model, n, n_p, n_f, n_s, hist, smax, smin)
         with torch.no_grad():
-            want = pr.predict_table(model, n, n_p, n_f, n_s, hist, smax, smin)
+            pt32 = pr.predict_table(model, n, n_p, n_f, n_s, hist, smax, smin)
         got = nat.predict(n, hist, smax, smin)
-        err = float((got - want).abs().max() / want.abs().max())
-        assert err <= TOL, err
+        scale = float(ref.abs().max())
+        e_nat, e_pt = float((got - ref).abs().max()) / scale, float((pt32 - ref).abs().max()) / scale
+        assert e_nat <= TOL and e_nat <= 1.5 * e_pt + 2e-6, (e_nat, e_pt)
+        assert float((got - pt32).abs().max()) / scale <= 1e-4  # the bar the PyTorch GPU path is held to elsewhere
         assert torch.equal(got, nat.predict(n, hist, smax, smin))  # deterministic: fixed summation orders
 
 

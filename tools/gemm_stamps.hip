@@ -35,7 +35,7 @@ int main() {
                       (int)kGemmLds);
   GemmArgs g{};
   g.A = dA; g.lda = K; g.B = dB; g.ldb = ldb; g.M = M; g.N = N; g.K = K; g.k_per_split = kps;
-  g.smax = 1e-3; g.sden = 2e-3; g.Cpart = dC; g.ldc = N; g.stamps = dS;
+  g.smax = 1e-3; g.sden = 2e-3; g.srcp = 1.0 / g.sden; g.Cpart = dC; g.ldc = N; g.stamps = dS;
   hipEvent_t a, b;
   hipEventCreate(&a);
   hipEventCreate(&b);

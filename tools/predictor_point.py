@@ -41,6 +41,22 @@ for I in sizes:
         for _ in range(4):
             want = graph(n, hist).clone()
     err = float((got - want).abs().max() / want.abs().max())
+    # both against the same model evaluated in fp64 (weights widened, history not rounded to fp32)
+    import copy
+
+    m64 = copy.deepcopy(model).double()
+    with torch.no_grad():
+        past, fut = pr._phase_indices(n, n_p, n_f, n_s)
+        import numpy as np
+
+        X = pr.scale_forward(hist[torch.as_tensor(np.stack(past), device="cuda")], smax, smin)
+        Y = pr.scale_it_back(pr.model_predict("cuda", m64, X, n_f), smax, smin)
+        ref = torch.zeros_like(want)
+        ref[torch.as_tensor(np.stack(fut), device="cuda").reshape(-1)] = Y.reshape(-1, I)
+    e_nat = float((got - ref).abs().max() / ref.abs().max())
+    e_pt = float((want - ref).abs().max() / ref.abs().max())
+    print(f"input_size {I:5d}: against the fp64 evaluation of the model: native {e_nat:.2e}, PyTorch-ROCm fp32 {e_pt:.2e} "
+          "(largest difference / range)", flush=True)
 
     def ms(fn, reps=50):
         for _ in range(3):
