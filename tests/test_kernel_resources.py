@@ -42,3 +42,29 @@ def test_step_kernels_fit_their_register_budget_without_spills():
         # persistent_max_blocks, MI355X_MICROARCH.md "Residency")
         assert r["sgpr"] <= 112, (name, r)
 
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="hipcc not installed")
+def test_predictor_kernels_keep_their_staging_in_registers():
+    """The predictor's GEMM runs two workgroups of four waves per CU (256 registers per lane) and the H = 50 recurrence
+    kernel keeps a gate row's weights in registers.  Three times during their writing an innocent-looking change left an
+    array in scratch memory (an array of HIP float4 structs, an array inside a struct, a lambda called twice and therefore
+    not inlined): one global load at a time, each waited for - parity intact, 2-4x slower."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "kernel_resources.py"), "--file=saa_predictor.hip"],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr
+    rows = {}
+    for ln in out.stdout.splitlines()[1:]:
+        f = ln.split()
+        rows[" ".join(f[:-6])] = dict(zip(("sgpr", "vgpr", "sspill", "vspill", "scratch", "occ"), (int(v) for v in f[-6:])))
+    gemm = {k: v for k, v in rows.items() if "gemm_nt_kernel" in k}
+    lstm = {k: v for k, v in rows.items() if "lstm_recurrence_kernel" in k}
+    assert len(gemm) == 2 and len(lstm) == 2, rows
+    for name, r in rows.items():
+        assert r["vspill"] == 0 and r["scratch"] == 0, (name, r)
+    for name, r in gemm.items():
+        assert r["vgpr"] <= 256 and r["occ"] == 2 and r["sspill"] == 0, (name, r)
+    # (the recurrence kernel's thirteen argument pointers do not all fit the scalar file next to its loop state: some live
+    # in lanes of a vector register between their uses - register to register, no memory traffic)
+    for name, r in lstm.items():
+        assert r["vgpr"] <= 256, (name, r)

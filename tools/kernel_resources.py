@@ -1,13 +1,15 @@
 #!/usr/bin/env python3
-"""Diagnostic: registers / spills / scratch / LDS of every kernel in saa_kernels.hip (hipcc -Rpass-analysis)."""
+"""Diagnostic: registers / spills / scratch / LDS of every kernel in saa_kernels.hip, or of the file named by
+``--file=saa_predictor.hip`` (hipcc -Rpass-analysis)."""
 import os
 import re
 import subprocess
 import sys
 
 csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "synchronization_avoiding_algorithms_amd", "csrc")
+src = ([a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--file=")] or ["saa_kernels.hip"])[0]
 cmd = ["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-c",
-       "saa_kernels.hip", "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage", *sys.argv[1:]]
+       src, "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage", *[a for a in sys.argv[1:] if not a.startswith("--file=")]]
 err = subprocess.run(cmd, cwd=csrc, capture_output=True, text=True).stderr
 cur = None
 rows = {}
@@ -17,7 +19,7 @@ for ln in err.splitlines():
     if not m:
         continue
     if m.group(1) == "Function Name":
-        cur = subprocess.run(["c++filt", m.group(2)], capture_output=True, text=True).stdout.strip().split("(")[0]
+        cur = subprocess.run(["c++filt", m.group(2)], capture_output=True, text=True).stdout.strip().replace("(anonymous namespace)::", "").split("(")[0]
         rows[cur] = {}
     elif cur:
         rows[cur][m.group(1).split(" [")[0]] = m.group(2)
