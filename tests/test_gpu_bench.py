@@ -82,6 +82,11 @@ def test_headline_at_the_drivers_flags_is_warm():
     # the practical HBM ceiling comes from the library's own 16-byte-per-lane copy kernel (the guide: 6.29 TB/s)
     assert 5000 < roof["measured_copy_GBps"] < 8000, roof["measured_copy_GBps"]
     assert out["legs"]["roofline"] == "done" and out["legs"]["cpu_baseline"].startswith("skipped")
+    # configs[4]'s predictor at an interior rank's width on the library's own kernels, beside the PyTorch-ROCm route
+    pred = out["predictor"]
+    assert out["legs"]["predictor"] == "done" and pred["roofline"]["bound"] == "mfma", out["legs"]
+    assert pred["ms_per_window"] < 1.5 and pred["speedup_vs_pytorch_rocm"] > 3, pred
+    assert pred["max_difference_vs_pytorch_rocm_over_range"] < 1e-4, pred
     kernel_rate = 1028850 / (roof["us_per_step"] * 1e-6)
     assert out["value"] > kernel_rate / 1.5, (out["value"], kernel_rate)
     assert out["timed_calls"] * out["steps"] * out["ms_per_step"] >= 45.0  # the timed region lasted >= ~50 ms
