@@ -193,12 +193,12 @@ def build_rank_solver(mesh, n_parts, rank, device, block_nodes=0, threads=0):
     CFL step; inside a process group PartitionedSolver takes the minimum over the ranks)."""
     import synchronization_avoiding_algorithms_amd as saa
     from synchronization_avoiding_algorithms_amd import fem_setup as fs
-    from synchronization_avoiding_algorithms_amd.mesh import clamp_nodes, slab_partition
+    from synchronization_avoiding_algorithms_amd.mesh import slab_partition
 
     lmd, mu = fs.lame(E, NU)
     epart = slab_partition(mesh, n_parts) if n_parts > 1 else np.zeros(len(mesh.tets), dtype=np.int64)
-    lay, gshared, l_M, F_rankwise, dt = fs.rank_problem(mesh.points, mesh.tets, clamp_nodes(mesh), epart, rank, n_parts,
-                                                         E, NU, RHO, FZ, GAMMA, device)
+    lay, gshared, l_M, F_rankwise, dt = fs.rank_problem(mesh.points, mesh.tets, None, epart, rank, n_parts,
+                                                         E, NU, RHO, FZ, GAMMA, device, facets=mesh.triangles)
     sol = saa.HipExplicitSolver(mesh.points[lay.nodes], lay.cells_local, l_M, F_rankwise, lay.dirichlet_dofs, lmd, mu,
                                 dt, ALPHA, shared_local=lay.shared_local, shared_slots=lay.shared_slots,
                                 n_global_shared=len(gshared), device=device, block_nodes=block_nodes, threads=threads)

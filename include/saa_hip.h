@@ -260,6 +260,31 @@ int saa_synchronize(saa_solver *s);
 int saa_device_copy_bandwidth(int32_t device, int64_t n_bytes, int32_t reps, double *bytes_per_s);
 
 /*
+ * Partition bookkeeping of ONE rank on the GPU: what Data_prepare.py:104-144 derives from the element partition `epart`
+ * (`recvbuf`, Data_prepare.py:97-101) through Tools/Distributed_tools.py - `rankwise_dist` (:14-24: the rank's elements
+ * and its nodes in first-touch order), `find_shared_nodes` (:29-40) + `sort_shared` (:44-51: `shared_nodes`,
+ * `Global_shared`), `local_mat_node` (:66-73: local connectivity), `Dirichlet_rank_dist` (:55-62) - and the clamp detection
+ * of Data_prepare.py:127-136 (nodes of boundary facets with all |x| < tol), in the reference's orderings, as O(N) device
+ * passes + radix sorts instead of O(N^2) list scans.  Host arrays in; the results are held by the handle until copied out.
+ *   tets   (n_elems, 4) GLOBAL node ids of the whole mesh, epart (n_elems) part of every element, 0 <= rank < n_parts;
+ *   xyz (n_nodes, 3) and facets (n_facets, 3) may be null / 0: no clamp detection then.
+ * saa_topology_sizes fills sizes[6] = { elements, nodes, shared nodes of the rank, Global_shared, clamped nodes of the
+ * mesh, clamped nodes of the rank }; saa_topology_get copies into caller buffers of those sizes (any pointer may be null):
+ *   elements (ascending), nodes (first-touch order), cells_local (elements x 4, local ids), shared_nodes (global ids,
+ *   find_shared_nodes' order), shared_local, shared_slots (position in Global_shared), global_shared (sorted),
+ *   dirichlet_nodes (global ids, first-seen order over the facets), dirichlet_local (local ids, ascending).
+ */
+typedef struct saa_topology saa_topology;
+int saa_topology_build(int32_t device, int32_t n_nodes, int32_t n_elems, const int32_t *tets, const int32_t *epart, int32_t rank,
+                       int32_t n_parts, const double *xyz, int32_t n_facets, const int32_t *facets, double clamp_tol,
+                       saa_topology **out);
+int saa_topology_sizes(const saa_topology *t, int32_t *sizes);
+int saa_topology_get(const saa_topology *t, int32_t *elements, int32_t *nodes, int32_t *cells_local, int32_t *shared_nodes,
+                     int32_t *shared_local, int32_t *shared_slots, int32_t *global_shared, int32_t *dirichlet_nodes,
+                     int32_t *dirichlet_local);
+int saa_topology_destroy(saa_topology *t);
+
+/*
  * Shared-node predictor: the per-rank LSTM encoder-decoder of Tools/DNN_tools.py:16-98 (2-layer bidirectional encoder of
  * width hidden_size, decoder LSTM of width 2*hidden_size + Linear) evaluated for all filter_size phase offsets of one
  * prediction window - what Tools/DNN_prediction.py:38-55 (`encoder_decoder_predictor`) computes with filter_size

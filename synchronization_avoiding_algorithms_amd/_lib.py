@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("SAA_LIB_PATH") or os.path.join(_HERE, "libsaa_hip.so"
 #: only; built on request (``build_library(diag=True)``), loaded through SAA_LIB_PATH, never by the package itself
 DIAG_LIB_PATH = os.path.join(_HERE, "libsaa_hip_diag.so")
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "saa_hip.h")
-SOURCES = ["saa_plan.cpp", "saa_partition.cpp", "saa_kernels.hip", "saa_setup.hip", "saa_predictor.hip", "saa_api.cpp"]
+SOURCES = ["saa_plan.cpp", "saa_partition.cpp", "saa_kernels.hip", "saa_setup.hip", "saa_predictor.hip", "saa_topology.hip", "saa_api.cpp"]
 HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics", "-ldl"]
 
 ABI_VERSION = 8  # what saa_abi_version() of a matching library returns (include/saa_hip.h)
@@ -114,6 +114,11 @@ SIGNATURES = {
     "saa_predictor_predict": (C.c_int, [_H, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_double, C.c_double,
                                         C.c_void_p, C.c_int64, C.c_void_p]),
     "saa_predictor_destroy": (C.c_int, [_H]),
+    "saa_topology_build": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _ip, _ip, C.c_int32, C.c_int32, _dp, C.c_int32, _ip,
+                                     C.c_double, C.POINTER(_H)]),
+    "saa_topology_sizes": (C.c_int, [_H, _ip]),
+    "saa_topology_get": (C.c_int, [_H, _ip, _ip, _ip, _ip, _ip, _ip, _ip, _ip, _ip]),
+    "saa_topology_destroy": (C.c_int, [_H]),
 }
 
 _lib = None

@@ -20,6 +20,7 @@
 #include "saa_plan.h"
 #include "saa_predictor.h"
 #include "saa_setup.h"
+#include "saa_topology.h"
 
 namespace {
 
@@ -636,7 +637,7 @@ extern "C" {
 
 const char *saa_last_error(void) { return g_last_error.c_str(); }
 
-int32_t saa_abi_version(void) { return 8; }  // 4: saa_part_mesh_kway, saa_setup_fields; 5: saa_set_deterministic; 6: saa_device_copy_bandwidth; 7: saa_plan_stats grew; 8: saa_predictor_*
+int32_t saa_abi_version(void) { return 8; }  // 4: saa_part_mesh_kway, saa_setup_fields; 5: saa_set_deterministic; 6: saa_device_copy_bandwidth; 7: saa_plan_stats grew; 8: saa_predictor_*, saa_topology_*
 
 int saa_device_copy_bandwidth(int32_t device, int64_t n_bytes, int32_t reps, double *bytes_per_s) {
   if (!bytes_per_s || n_bytes < 16 || reps < 1) return fail(SAA_E_ARG, "saa_device_copy_bandwidth: bad argument");
@@ -1502,6 +1503,64 @@ int saa_time_steps(saa_solver *s, int32_t nsteps, double *elapsed_ms) {
   (void)hipEventDestroy(a);
   (void)hipEventDestroy(b);
   return rc;
+}
+
+// ---- partition bookkeeping of one rank (saa_topology.hip) ------------------------------------------------------
+struct saa_topology {
+  saa::RankTopology t;
+};
+
+int saa_topology_build(int32_t device, int32_t n_nodes, int32_t n_elems, const int32_t *tets, const int32_t *epart, int32_t rank,
+                       int32_t n_parts, const double *xyz, int32_t n_facets, const int32_t *facets, double clamp_tol,
+                       saa_topology **out) {
+  if (!out) return fail(SAA_E_ARG, "saa_topology_build: null output");
+  *out = nullptr;
+  saa_topology *t = new (std::nothrow) saa_topology;
+  if (!t) return fail(SAA_E_HIP, "saa_topology_build: out of host memory");
+  std::string err;
+  hipError_t e;
+  try {
+    e = saa::rank_topology(device, n_nodes, n_elems, tets, epart, rank, n_parts, xyz, n_facets, facets, clamp_tol, &t->t, err);
+  } catch (const std::bad_alloc &) {
+    delete t;
+    return fail(SAA_E_HIP, "saa_topology_build: out of host memory");
+  }
+  if (e != hipSuccess) {
+    delete t;
+    return err.empty() ? fail(SAA_E_HIP, std::string("saa_topology_build: ") + hipGetErrorString(e)) : fail(SAA_E_ARG, err);
+  }
+  *out = t;
+  return SAA_OK;
+}
+
+int saa_topology_sizes(const saa_topology *t, int32_t *sizes) {
+  if (!t || !sizes) return fail(SAA_E_ARG, "saa_topology_sizes: null argument");
+  const saa::RankTopology &r = t->t;
+  const size_t n[6] = {r.elements.size(), r.nodes.size(), r.shared_nodes.size(), r.global_shared.size(),
+                       r.dirichlet_nodes.size(), r.dirichlet_local.size()};
+  for (int i = 0; i < 6; ++i) sizes[i] = static_cast<int32_t>(n[i]);
+  return SAA_OK;
+}
+
+int saa_topology_get(const saa_topology *t, int32_t *elements, int32_t *nodes, int32_t *cells_local, int32_t *shared_nodes,
+                     int32_t *shared_local, int32_t *shared_slots, int32_t *global_shared, int32_t *dirichlet_nodes,
+                     int32_t *dirichlet_local) {
+  if (!t) return fail(SAA_E_ARG, "saa_topology_get: null handle");
+  const saa::RankTopology &r = t->t;
+  const std::pair<const std::vector<int32_t> *, int32_t *> io[9] = {
+      {&r.elements, elements},         {&r.nodes, nodes},
+      {&r.cells_local, cells_local},   {&r.shared_nodes, shared_nodes},
+      {&r.shared_local, shared_local}, {&r.shared_slots, shared_slots},
+      {&r.global_shared, global_shared}, {&r.dirichlet_nodes, dirichlet_nodes},
+      {&r.dirichlet_local, dirichlet_local}};
+  for (const auto &p : io)
+    if (p.second && !p.first->empty()) std::memcpy(p.second, p.first->data(), p.first->size() * sizeof(int32_t));
+  return SAA_OK;
+}
+
+int saa_topology_destroy(saa_topology *t) {
+  delete t;
+  return SAA_OK;
 }
 
 // ---- shared-node predictor (saa_predictor.hip) ----------------------------------------------------------------

@@ -45,16 +45,20 @@ class PartitionedSolver:
         self.group = process_group
         points = np.ascontiguousarray(points, dtype=np.float64)
         cells = np.asarray(cells, dtype=np.int64)
-        dn = np.asarray(facets_or_dirichlet_nodes)
+        dn, facets = np.asarray(facets_or_dirichlet_nodes), None
         if dn.ndim == 2:  # triangle facets: detect the clamp like Data_prepare.py:127-136
-            from .mesh import Mesh
+            if setup_fields is None:  # on the device, with the rest of the layout (saa_topology_build)
+                dn, facets = None, dn
+            else:
+                from .mesh import Mesh
 
-            dn = clamp_nodes(Mesh(points, {"tetra": cells, "triangle": dn}))
+                dn = clamp_nodes(Mesh(points, {"tetra": cells, "triangle": dn}))
         self.lmd, self.mu = fs.lame(E, nu)
-        # this rank's layout only; lumped mass / load / shortest edge from the HIP set-up kernels on the elements that
-        # touch this rank's nodes (``setup_fields`` is injectable for the CPU-only tests of this orchestration)
+        # this rank's layout only, from the topology kernels; lumped mass / load / shortest edge from the HIP set-up
+        # kernels on the elements that touch this rank's nodes (``setup_fields`` is injectable for the CPU-only tests of
+        # this orchestration, which then take the NumPy layout as well)
         self.layout, self.global_shared, l_M, F_rankwise, dt_local = fs.rank_problem(
-            points, cells, dn, epart, rank, world, E, nu, rho, fz, gamma, device, setup_fields)
+            points, cells, dn, epart, rank, world, E, nu, rho, fz, gamma, device, setup_fields, facets=facets)
         lay = self.layout
         # dt = min over the ranks of the local CFL steps (Data_prepare.py:147-154)
         self.dt = dt_local

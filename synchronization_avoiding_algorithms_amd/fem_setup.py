@@ -241,6 +241,50 @@ def build_rank_layout(cells: np.ndarray, epart: np.ndarray, rank: int, n_parts: 
     return layout, global_shared
 
 
+def device_rank_layout(cells, epart, rank, n_parts, n_nodes, dirichlet_nodes=None, points=None, facets=None, device=0,
+                       clamp_tol=1e-9):
+    """:func:`build_rank_layout` on the GPU (``saa_topology_build``, ``csrc/saa_topology.hip``): holder masks and first-touch
+    keys by integer atomics, the reference's orderings by radix sorts.  Dirichlet nodes either as a list
+    (``dirichlet_nodes``) or detected on the device from ``points`` and the boundary ``facets`` (triangles with all
+    ``|x| < clamp_tol``, ``Data_prepare.py:127-136``).  Returns ``(RankLayout, Global_shared, dirichlet_nodes)``."""
+    import ctypes as C
+
+    from . import _lib
+
+    lib = _lib.load()
+    tets = np.ascontiguousarray(cells, dtype=np.int32).reshape(-1, 4)
+    parts = np.ascontiguousarray(epart, dtype=np.int32)
+    ip, dp = C.POINTER(C.c_int32), C.POINTER(C.c_double)
+    detect = facets is not None and dirichlet_nodes is None
+    if detect:
+        pts = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
+        fac = np.ascontiguousarray(facets, dtype=np.int32).reshape(-1, 3)
+    h = C.c_void_p()
+    _lib.check(lib.saa_topology_build(int(device), int(n_nodes), len(tets), tets.ctypes.data_as(ip) if len(tets) else None,
+                                      parts.ctypes.data_as(ip) if len(parts) else None, int(rank), int(n_parts),
+                                      pts.ctypes.data_as(dp) if detect and len(fac) else None, len(fac) if detect else 0,
+                                      fac.ctypes.data_as(ip) if detect and len(fac) else None, float(clamp_tol), C.byref(h)))
+    try:
+        sizes = (C.c_int32 * 6)()
+        _lib.check(lib.saa_topology_sizes(h, sizes))
+        n_le, n_ln, n_sh, n_gs, n_d, n_dl = (int(v) for v in sizes)
+        out = [np.empty(n, dtype=np.int32) for n in (n_le, n_ln, 4 * n_le, n_sh, n_sh, n_sh, n_gs, n_d, n_dl)]
+        _lib.check(lib.saa_topology_get(h, *[a.ctypes.data_as(ip) if a.size else None for a in out]))
+    finally:
+        lib.saa_topology_destroy(h)
+    elements, nodes, cells_local, shared, shared_local, shared_slots, gshared, dnodes, dlocal = out
+    nodes = nodes.astype(np.int64)
+    if not detect:
+        dnodes = np.asarray(dirichlet_nodes if dirichlet_nodes is not None else [], dtype=np.int64)
+        is_d = np.zeros(n_nodes, dtype=bool)
+        is_d[dnodes] = True
+        dlocal = np.nonzero(is_d[nodes])[0]
+    layout = RankLayout(rank=rank, elements=elements.astype(np.int64), nodes=nodes, cells_local=cells_local.reshape(-1, 4),
+                        shared_nodes=shared.astype(np.int64), shared_local=shared_local, shared_slots=shared_slots,
+                        dirichlet_dofs=node_to_dof(dlocal).astype(np.int32), loc_dof_shared=node_to_dof(shared_local))
+    return layout, gshared.astype(np.int64), np.asarray(dnodes, dtype=np.int64)
+
+
 def rank_fields(points, cells, layout: RankLayout, rho, fz, device=0, setup=None):
     """``l_M``, ``F_rankwise`` ``(3 n_local, 1)`` of this rank (``Data_prepare.py:200-202``: the GLOBAL lumped mass and
     load restricted to the rank's nodes, so shared nodes carry the contributions of the other ranks' elements too) and
@@ -258,10 +302,18 @@ def rank_fields(points, cells, layout: RankLayout, rho, fz, device=0, setup=None
     return lumped[dof], load[dof], min_edge
 
 
-def rank_problem(points, cells, dirichlet_nodes, epart, rank, n_parts, E, nu, rho, fz, gamma, device=0, setup=None):
+def rank_problem(points, cells, dirichlet_nodes, epart, rank, n_parts, E, nu, rho, fz, gamma, device=0, setup=None, facets=None):
     """Everything rank ``rank`` needs to create its solver (``Data_prepare.py:104-204`` for one rank): its layout,
     ``Global_shared``, ``l_M`` / ``F_rankwise`` from the set-up kernels and its LOCAL CFL step - the caller takes the
-    minimum over the ranks (``Data_prepare.py:148-154``)."""
-    layout, global_shared = build_rank_layout(cells, epart, rank, n_parts, len(points), dirichlet_nodes)
+    minimum over the ranks (``Data_prepare.py:148-154``).  On the GPU (``setup`` left at its default) the layout comes from
+    the topology kernels (:func:`device_rank_layout`); with ``dirichlet_nodes=None`` and the boundary ``facets`` given the
+    clamped nodes are detected there too.  A host ``setup`` (CPU tests of the orchestration) keeps the NumPy layout."""
+    if setup is None:
+        layout, global_shared, _ = device_rank_layout(cells, epart, rank, n_parts, len(points), dirichlet_nodes, points, facets,
+                                                      device)
+    else:
+        if dirichlet_nodes is None:
+            raise ValueError("the host layout needs the list of clamped nodes")
+        layout, global_shared = build_rank_layout(cells, epart, rank, n_parts, len(points), dirichlet_nodes)
     l_M, F_rankwise, min_edge = rank_fields(points, cells, layout, rho, fz, device, setup)
     return layout, global_shared, l_M, F_rankwise, dt_from_min_edge(min_edge, E, nu, rho, gamma)

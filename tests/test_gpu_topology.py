@@ -1,0 +1,97 @@
+"""The topology kernels (csrc/saa_topology.hip, C ABI saa_topology_*) against the NumPy restatement of the reference's
+partition bookkeeping (fem_setup.build_rank_layout / build_layouts, themselves pinned to the reference's orderings by
+tests/test_oracle_golden.py and the two-rank fixtures): integer work - every list equal, element by element."""
+import numpy as np
+import pytest
+
+from synchronization_avoiding_algorithms_amd import _lib
+from synchronization_avoiding_algorithms_amd import fem_setup as fs
+from synchronization_avoiding_algorithms_amd.mesh import clamp_nodes, graph_partition, slab_partition, structured_beam
+
+pytestmark = pytest.mark.gpu
+
+
+def _same(dev, host):
+    for name in ("elements", "nodes", "cells_local", "shared_nodes", "shared_local", "shared_slots", "dirichlet_dofs",
+                 "loc_dof_shared"):
+        a, b = np.asarray(getattr(dev, name)), np.asarray(getattr(host, name))
+        assert a.shape == b.shape and np.array_equal(a, b), name
+
+
+def _check(mesh, epart, n_parts, ranks=None):
+    dn = clamp_nodes(mesh)
+    for r in (range(n_parts) if ranks is None else ranks):
+        host, gs_h = fs.build_rank_layout(mesh.tets, epart, r, n_parts, len(mesh.points), dn)
+        # clamped nodes detected on the device from the boundary facets ...
+        dev, gs_d, dn_d = fs.device_rank_layout(mesh.tets, epart, r, n_parts, len(mesh.points), None, mesh.points,
+                                                mesh.triangles)
+        _same(dev, host)
+        assert np.array_equal(gs_d, gs_h) and np.array_equal(dn_d, dn)
+        # ... or handed over as a list
+        dev2, gs2, _ = fs.device_rank_layout(mesh.tets, epart, r, n_parts, len(mesh.points), dn)
+        _same(dev2, host)
+        assert np.array_equal(gs2, gs_h)
+
+
+def test_reference_mesh_two_and_three_parts(beam_coarse):
+    _check(beam_coarse, slab_partition(beam_coarse, 2), 2)
+    for k in (2, 3, 5):
+        _check(beam_coarse, graph_partition(beam_coarse, k), k)
+
+
+def test_slabs_and_graph_partitions_of_a_beam():
+    mesh = structured_beam(6)
+    _check(mesh, slab_partition(mesh, 8), 8)
+    epart = graph_partition(mesh, 8)  # nodes with three and four holders
+    _check(mesh, epart, 8)
+    # one part: nothing shared
+    lay, gs, dn = fs.device_rank_layout(mesh.tets, np.zeros(len(mesh.tets), dtype=np.int64), 0, 1, len(mesh.points), None,
+                                        mesh.points, mesh.triangles)
+    assert len(gs) == 0 and len(lay.shared_nodes) == 0 and len(lay.nodes) == len(mesh.points) and len(dn) == 49
+
+
+def test_shuffled_numbering_and_more_than_64_parts():
+    """Scrambled node / element numbering (first-touch orders far from the identity) and 70 parts: two mask words."""
+    from test_gpu_parity import _scrambled_mesh
+
+    mesh = _scrambled_mesh(5, 3)[0]
+    rng = np.random.default_rng(0)
+    _check(mesh, slab_partition(mesh, 4), 4)
+    epart = rng.integers(0, 70, size=len(mesh.tets))  # a random assignment: almost every node is shared, many holders
+    _check(mesh, epart, 70, ranks=(0, 17, 63, 64, 69))
+    # a part without elements: empty lists, no failure
+    epart = np.where(epart == 5, 6, epart)
+    lay, gs, _ = fs.device_rank_layout(mesh.tets, epart, 5, 70, len(mesh.points), [])
+    host, gs_h = fs.build_rank_layout(mesh.tets, epart, 5, 70, len(mesh.points), [])
+    assert len(lay.elements) == 0 and len(lay.nodes) == 0 and np.array_equal(gs, gs_h)
+
+
+def test_full_size_partition_in_seconds():
+    """The interior rank of the 8-way partition of the 8.2M-tet beam: device layout == host layout."""
+    import time
+
+    mesh = structured_beam(38)
+    epart = slab_partition(mesh, 8)
+    dn = clamp_nodes(mesh)
+    t0 = time.perf_counter()
+    dev, gs_d, dn_d = fs.device_rank_layout(mesh.tets, epart, 3, 8, len(mesh.points), None, mesh.points, mesh.triangles)
+    t_dev = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    host, gs_h = fs.build_rank_layout(mesh.tets, epart, 3, 8, len(mesh.points), dn)
+    t_host = time.perf_counter() - t0
+    _same(dev, host)
+    assert np.array_equal(gs_d, gs_h) and np.array_equal(dn_d, dn)
+    print(f"rank 3 of 8, {len(mesh.tets)} tets: device {t_dev:.2f} s (incl. the copies of the mesh), NumPy {t_host:.2f} s")
+
+
+def test_bad_input_is_refused():
+    mesh = structured_beam(2)
+    epart = slab_partition(mesh, 2)
+    bad = mesh.tets.copy()
+    bad[3, 1] = len(mesh.points)
+    with pytest.raises(_lib.SaaError, match="element node outside"):
+        fs.device_rank_layout(bad, epart, 0, 2, len(mesh.points), [])
+    with pytest.raises(_lib.SaaError, match="part outside"):
+        fs.device_rank_layout(mesh.tets, epart + 1, 0, 2, len(mesh.points), [])
+    with pytest.raises(_lib.SaaError, match="bad argument"):
+        fs.device_rank_layout(mesh.tets, epart, 2, 2, len(mesh.points), [])
