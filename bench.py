@@ -519,7 +519,8 @@ def predictor_leg(device_index):
                          "note": "whole window (four launches) against the dense f32 matrix peak; the input-projection "
                                  "GEMM alone (21.9 of the 28.6 GFLOP): 77 TFLOP/s = 0.49 "
                                  "(profiles/r03_predictor_kernel_trace_saa.csv)"},
-            "share_of_a_3000_step_window": "0.49 ms against ~26 ms of exchange-free stepping per rank (PyTorch-ROCm: 4.7 ms)"}
+            "share_of_a_3000_step_window": f"{t_nat:.2f} ms against ~26 ms of exchange-free stepping per rank "
+                                           f"(PyTorch-ROCm: {t_pt:.1f} ms)"}
 
 
 def launch_ranks(args):

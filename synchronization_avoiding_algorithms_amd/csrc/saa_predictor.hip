@@ -133,7 +133,7 @@ __global__ void __launch_bounds__(kGemmThreads) __attribute__((amdgpu_waves_per_
     }
   };
   const float *ap = As + (16 * wm + (lane & 15)) * kLd + 4 * (lane >> 4), *bp = Bs + (lane & 15) * kLd + 4 * (lane >> 4);
-  auto multiply = [&]() __attribute__((always_inline)) {
+  auto multiply = [&](bool second_group) __attribute__((always_inline)) {
     f32x4 a0, a1, b0[kT], b1[kT];
     a0 = *reinterpret_cast<const f32x4 *>(ap);
 #pragma unroll
@@ -147,10 +147,12 @@ __global__ void __launch_bounds__(kGemmThreads) __attribute__((amdgpu_waves_per_
 #pragma unroll
       for (int t = 0; t < kT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[s], b0[t][s], acc[t], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
+    if (second_group) {  // (the output GEMM has K = 2H = 100: the second half of its last chunk is padding)
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
+      for (int s = 0; s < 4; ++s)
 #pragma unroll
-      for (int t = 0; t < kT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[s], b1[t][s], acc[t], 0, 0, 0);
+        for (int t = 0; t < kT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[s], b1[t][s], acc[t], 0, 0, 0);
+    }
     __builtin_amdgcn_sched_barrier(0);
   };
 #ifdef SAA_GEMM_STAMPS
@@ -173,7 +175,7 @@ __global__ void __launch_bounds__(kGemmThreads) __attribute__((amdgpu_waves_per_
     // that are live across a branch end up in scratch memory as well)
     load_chunk(k0 + kKC < kend ? k0 + kKC : kbeg);
     GSTAMP(2)
-    multiply();
+    multiply(k0 + 16 < kend);
     GSTAMP(3)
     __syncthreads();
     GSTAMP(4)
@@ -184,19 +186,34 @@ __global__ void __launch_bounds__(kGemmThreads) __attribute__((amdgpu_waves_per_
       g.stamps[(((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 32 + wm * 8 + j] = T[j];
 #endif
   // C/D layout of the 16x16 forms: column = lane & 15, row = 4 * (lane >> 4) + register
+  if (TABLE) {
+    // Y * (max - min) + max as two fp32 operations, each rounded (DNN_tools.py:277-279: a tensor times a Python scalar,
+    // then plus one) - no contraction into an FMA; the bias of all thirteen columns requested before the first store (a
+    // load inside the store loop is waited for together with every store in front of it: vmcnt counts both)
+#pragma clang fp contract(off)
+    float bias[kT];
 #pragma unroll
-  for (int t = 0; t < kT; ++t) {
-    const int col = n0 + 16 * t + (lane & 15);
+    for (int t = 0; t < kT; ++t) bias[t] = g.bias[min(n0 + 16 * t + (lane & 15), g.N - 1)];
+    double *trow = g.table + (int64_t)(m0 + 16 * wm + 4 * (lane >> 4)) * g.ldt + n0 + (lane & 15);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = m0 + 16 * wm + 4 * (lane >> 4) + r;
-      if (row < g.M && col < g.N) {
-        if (TABLE) {
-          const float y = __fadd_rn(__fmul_rn(__fadd_rn(acc[t][r], g.bias[col]), g.range32), g.max32);
-          g.table[(int64_t)row * g.ldt + col] = (double)y;
-        } else {
-          g.Cpart[((int64_t)blockIdx.z * g.M + row) * g.ldc + col] = acc[t][r];
-        }
+    for (int t = 0; t < kT; ++t) {
+      const int col = n0 + 16 * t + (lane & 15);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + 16 * wm + 4 * (lane >> 4) + r;
+        const float y = (acc[t][r] + bias[t]) * g.range32 + g.max32;
+        if (row < g.M && col < g.N) trow[(int64_t)r * g.ldt + 16 * t] = (double)y;
+      }
+    }
+  } else {
+    float *crow = g.Cpart + ((int64_t)blockIdx.z * g.M + m0 + 16 * wm + 4 * (lane >> 4)) * g.ldc + n0 + (lane & 15);
+#pragma unroll
+    for (int t = 0; t < kT; ++t) {
+      const int col = n0 + 16 * t + (lane & 15);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + 16 * wm + 4 * (lane >> 4) + r;
+        if (row < g.M && col < g.N) crow[(int64_t)r * g.ldc + 16 * t] = acc[t][r];
       }
     }
   }

@@ -163,7 +163,7 @@ class NativePredictor:
     """The model on the HIP library's own kernels (``csrc/saa_predictor.hip``, C ABI ``saa_predictor_*``): the window's
     3000 history rows go through ONE f32 matrix-core GEMM (the fp64 scaling to [-1, 0] fused into its loads), the
     recurrences run one workgroup per phase with the decoder's output layer folded into its recurrent matrix, and a second
-    GEMM scales back and writes the fp64 table - four launches where the PyTorch path takes ~600 (4.7 ms -> 0.5 ms per
+    GEMM scales back and writes the fp64 table - four launches where the PyTorch path takes ~600 (4.7 ms -> 0.46 ms per
     window at 9126 inputs).  fp32 like the reference; another summation order than ATen's (round-off level differences)."""
 
     def __init__(self, model, n_past, n_future, filter_size, device_index=0):
