@@ -84,7 +84,7 @@ typedef struct saa_plan_stats {
 } saa_plan_stats;
 
 const char *saa_last_error(void);
-/* Library / ABI version; bumps when this header changes (2: peer exchange and resident-kernel entry points; 3: loop-back attach; 4: partitioner and set-up kernels; 5: deterministic mode). */
+/* Library / ABI version; bumps when this header changes (2: peer exchange and resident-kernel entry points; 3: loop-back attach; 4: partitioner and set-up kernels; 5: deterministic mode; 6: copy-bandwidth aid; 7: saa_plan_stats grew; 8: saa_predictor_*, saa_topology_*). */
 int32_t saa_abi_version(void);
 
 /* Element partition, one part per rank / GPU: the role of `_, epart = part_mesh_kway(size, eptr, eind)` (mgmetis /
