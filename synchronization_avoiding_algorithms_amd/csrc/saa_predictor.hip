@@ -293,7 +293,12 @@ __global__ void __launch_bounds__(lstm_threads(HC)) lstm_recurrence_kernel(LstmA
   // Every gate thread applies its gate's activation itself (rows [2H', 3H') of a block of 4H' rows are the cell candidate
   // g: tanh; i, f, o: the logistic function), so that the unit threads, two waves of seven, are left with one tanh.
   const bool enc_tanh = row >= 2 * H && row < 3 * H, dec_tanh = g >= 2 * D && g < 3 * D;
-  auto activate = [&](float v, bool is_tanh) { return is_tanh ? tanhf(v) : sigmoid_f32(v); };
+  // (tanh v = 2 s(2v) - 1 with the logistic function s: one exponential for either kind of gate and no divergent branch
+  // in the waves that hold both kinds; absolute error of an fp32 ulp of 1, which is what a gate value needs)
+  auto activate = [&](float v, bool is_tanh) {
+    const float sg = sigmoid_f32(is_tanh ? 2.0f * v : v);
+    return is_tanh ? 2.0f * sg - 1.0f : sg;
+  };
   auto encoder_cell = [&](int s, bool keep) {  // activated gates -> (c, h) of unit (ud, uj); time index of step s per direction
     if (unit_thread) {
       const float *q = gates + ud * H4 + uj;
