@@ -40,6 +40,9 @@ def scale_to_zero_one(X, Y):
 
 
 def _decode(model, X, n_future):
+    """Recursive decoding (``DNN_tools.py:119-127,185-193``): the decoder's own output is its next input."""
+    if X.is_cuda and _FOLDED and model.decoder.dropout.p == 0.0:
+        return _decode_folded(model, X, n_future)
     h, c = model.encoder(X)
     inp = X[:, -1, :]
     outs = []
@@ -47,6 +50,36 @@ def _decode(model, X, n_future):
         inp, h, c = model.decoder(inp, h, c)
         outs.append(inp)
     return torch.stack(outs, dim=1)
+
+
+_FOLDED = __import__("os").environ.get("SAA_TRAIN_FOLDED", "1") != "0"
+
+
+def _decode_folded(model, X, n_future):
+    """The same function of the same parameters with the decoder's feedback folded (GPU only; ``SAA_TRAIN_FOLDED=0``
+    keeps the literal form, which the CPU path always uses): from its second step on the decoder's input is
+    ``fc(h) = h W_fc^T + b_fc``, so ``gates = fc(h) W_ih^T + h W_hh^T + b = h (W_ih W_fc + W_hh)^T + (W_ih b_fc + b)``.
+    The folded matrix is formed once per pass (a 4D x I by I x D product) and every step is a D -> 4D product instead of
+    an I -> 4D one plus an ``nn.LSTM`` call; the outputs of all steps come from one product at the end.  Autograd
+    differentiates through the fold, so the gradients with respect to ``W_ih``, ``W_fc``, ``W_hh`` and the biases are those
+    of the literal form up to fp32 round-off (what predictor kernels do for inference, ``csrc/saa_predictor.hip``)."""
+    h, c = model.encoder(X)
+    h, c = h[0], c[0]
+    lstm, fc = model.decoder.lstm_decoder, model.decoder.fc
+    w_ih, w_hh, bias = lstm.weight_ih_l0, lstm.weight_hh_l0, lstm.bias_ih_l0 + lstm.bias_hh_l0
+    w_comb = torch.addmm(w_hh, w_ih, fc.weight)                       # (4D, D)
+    b_comb = torch.addmv(bias, w_ih, fc.bias)
+    gates = torch.addmm(bias, X[:, -1, :], w_ih.t()) + h @ w_hh.t()   # first step: the last history row (:224)
+    hs = []
+    for t in range(n_future):
+        if t > 0:
+            gates = torch.addmm(b_comb, h, w_comb.t())
+        gi, gf, gg, go = gates.chunk(4, dim=1)                        # PyTorch's gate order
+        c = torch.sigmoid(gf) * c + torch.sigmoid(gi) * torch.tanh(gg)
+        h = torch.sigmoid(go) * torch.tanh(c)
+        hs.append(h)
+    H = torch.stack(hs, dim=1)                                        # (B, n_future, D)
+    return torch.matmul(H, fc.weight.t()) + fc.bias
 
 
 class GraphedTrainStep:

@@ -97,3 +97,31 @@ def test_training_from_a_history_tensor_matches_the_file_path(tmp_path):
     # the time bound ends training early
     _, _, _, tl3, _ = tr.train_on_history(hist, 10, 4, 3, seed=3, hidden_size=8, num_epochs=10000, max_seconds=0.5)
     assert 1 <= len(tl3) < 10000
+
+
+def test_folded_decoding_is_the_same_function_forward_and_backward():
+    """``training._decode_folded`` (what the GPU path trains through: the decoder's feedback folded into its recurrent
+    matrix) against the literal recursion of DNN_tools.py:119-127, on the CPU where both run: outputs and the gradients
+    with respect to every parameter agree to fp32 round-off."""
+    import torch
+
+    from synchronization_avoiding_algorithms_amd import predictor as pr
+    from synchronization_avoiding_algorithms_amd import training as tr
+
+    torch.manual_seed(0)
+    model = pr.LSTM_encoder_decoder(30, 8)
+    X = torch.randn(5, 6, 30) * 0.3
+    folded = tr._decode_folded(model, X, 4)
+    h, c = model.encoder(X)
+    inp, outs = X[:, -1, :], []
+    for _ in range(4):
+        inp, h, c = model.decoder(inp, h, c)
+        outs.append(inp)
+    literal = torch.stack(outs, 1)
+    assert folded.shape == literal.shape and float((folded - literal).abs().max()) < 5e-7
+    ga = torch.autograd.grad(folded.square().mean(), list(model.parameters()))
+    gb = torch.autograd.grad(literal.square().mean(), list(model.parameters()))
+    scale = max(float(g.abs().max()) for g in gb)
+    assert max(float((a - b).abs().max()) for a, b in zip(ga, gb)) < 1e-6 * scale
+    # the CPU path itself keeps the literal form (the reference-pinned tolerances of test_training_golden.py are its)
+    assert torch.equal(tr._decode(model, X, 4), literal)
