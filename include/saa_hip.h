@@ -313,6 +313,23 @@ int saa_predictor_predict(saa_predictor *p, const double *hist_dev, int64_t hist
 
 int saa_predictor_destroy(saa_predictor *p);
 
+/* The pointwise part of one LSTM step and its backward pass, for the training loop (`model_train`, DNN_tools.py:103-165,
+ * whose decoder steps are `torch.nn.LSTM` calls, DNN_tools.py:73-79): device pointers, fp32, `gates` = (batch, 4*width)
+ * pre-activations in PyTorch's order i, f, g, o;  c = f c_prev + i g,  h = o tanh(c).  The forward keeps the activated gates
+ * (`act`, batch x 4*width) and tanh(c) for the backward, which turns the gradients with respect to h and c (either may be
+ * null = zero) into those with respect to the pre-activations and c_prev.  Enqueued on `stream`; capturable in a HIP graph. */
+int saa_lstm_cell_forward(int32_t device, int32_t batch, int32_t width, const float *gates_dev, const float *c_prev_dev,
+                          float *h_dev, float *c_dev, float *act_dev, float *tanh_c_dev, void *stream);
+int saa_lstm_cell_backward(int32_t device, int32_t batch, int32_t width, const float *act_dev, const float *tanh_c_dev,
+                           const float *c_prev_dev, const float *dh_dev, const float *dc_next_dev, float *dgates_dev,
+                           float *dc_prev_dev, void *stream);
+
+/* The three figures `model_train` / `model_test` accumulate per batch (DNN_tools.py:144-155,196-205) - the mean square error
+ * of `out_dev` against `target_dev` (n fp32 elements each), 1 - mse / mean((y - mean y)^2) and 1 - mse / mean(y^2) - added to
+ * the three doubles `sums3_dev`; sums in fp64.  `scratch3_dev`: three doubles, zero before the first call, left zero. */
+int saa_train_stats(int32_t device, int64_t n, const float *out_dev, const float *target_dev, double *scratch3_dev,
+                    double *sums3_dev, void *stream);
+
 /* Timing aid for bench.py: runs `nsteps` saa_step steps bracketed by HIP events recorded on the
  * handle's stream and returns the elapsed milliseconds (kernel time incl. launch gaps). */
 int saa_time_steps(saa_solver *s, int32_t nsteps, double *elapsed_ms);

@@ -1613,6 +1613,36 @@ int saa_predictor_destroy(saa_predictor *p) {
   return SAA_OK;
 }
 
+int saa_lstm_cell_forward(int32_t device, int32_t batch, int32_t width, const float *gates_dev, const float *c_prev_dev,
+                          float *h_dev, float *c_dev, float *act_dev, float *tanh_c_dev, void *stream) {
+  if (batch < 0 || width < 0 || (batch > 0 && width > 0 && (!gates_dev || !c_prev_dev || !h_dev || !c_dev || !act_dev || !tanh_c_dev)))
+    return fail(SAA_E_ARG, "saa_lstm_cell_forward: bad argument");
+  HIP_TRY(hipSetDevice(device));
+  HIP_TRY(saa::lstm_cell_forward(batch, width, gates_dev, c_prev_dev, h_dev, c_dev, act_dev, tanh_c_dev,
+                                 static_cast<hipStream_t>(stream)));
+  return SAA_OK;
+}
+
+int saa_lstm_cell_backward(int32_t device, int32_t batch, int32_t width, const float *act_dev, const float *tanh_c_dev,
+                           const float *c_prev_dev, const float *dh_dev, const float *dc_next_dev, float *dgates_dev,
+                           float *dc_prev_dev, void *stream) {
+  if (batch < 0 || width < 0 || (batch > 0 && width > 0 && (!act_dev || !tanh_c_dev || !c_prev_dev || !dgates_dev || !dc_prev_dev)))
+    return fail(SAA_E_ARG, "saa_lstm_cell_backward: bad argument");
+  HIP_TRY(hipSetDevice(device));
+  HIP_TRY(saa::lstm_cell_backward(batch, width, act_dev, tanh_c_dev, c_prev_dev, dh_dev, dc_next_dev, dgates_dev, dc_prev_dev,
+                                  static_cast<hipStream_t>(stream)));
+  return SAA_OK;
+}
+
+int saa_train_stats(int32_t device, int64_t n, const float *out_dev, const float *target_dev, double *scratch3_dev,
+                    double *sums3_dev, void *stream) {
+  if (n < 0 || (n > 0 && (!out_dev || !target_dev || !scratch3_dev || !sums3_dev)))
+    return fail(SAA_E_ARG, "saa_train_stats: bad argument");
+  HIP_TRY(hipSetDevice(device));
+  HIP_TRY(saa::train_stats(n, out_dev, target_dev, scratch3_dev, sums3_dev, static_cast<hipStream_t>(stream)));
+  return SAA_OK;
+}
+
 #ifdef SAA_DIAGNOSTICS
 // Diagnostic build only (libsaa_hip_diag.so, -DSAA_DIAGNOSTICS; never in the product library): time `nsteps`
 // launches of an ablated step kernel (state is not rotated; outputs are meaningless).  Used by tools/ablate.py only.

@@ -31,4 +31,15 @@ int predictor_device(const Predictor *p);
 hipError_t predictor_predict(Predictor *p, const double *hist, int64_t ld_hist, int64_t n, double scale_max, double scale_min,
                              double *table, int64_t ld_table, hipStream_t st);
 
+// Pointwise part of one LSTM step and its backward (device pointers, fp32, gates in PyTorch's order i, f, g, o), enqueued
+// on `st` - for the training pass of training.py.
+hipError_t lstm_cell_forward(int32_t B, int32_t D, const float *gates, const float *c_prev, float *h, float *c, float *act,
+                             float *tanh_c, hipStream_t st);
+hipError_t lstm_cell_backward(int32_t B, int32_t D, const float *act, const float *tanh_c, const float *c_prev, const float *dh,
+                              const float *dc_next, float *dgates, float *dc_prev, hipStream_t st);
+
+// sums[0..2] += (mse, 1 - mse / var(y), 1 - mse / mean(y^2)) of `out` against `y` (n fp32 elements each); `part` = three
+// doubles of scratch that are zero on entry and left zero.
+hipError_t train_stats(int64_t n, const float *out, const float *y, double *part, double *sums, hipStream_t st);
+
 }  // namespace saa

@@ -425,6 +425,90 @@ __global__ void __launch_bounds__(lstm_threads(HC)) lstm_recurrence_kernel(LstmA
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The pointwise part of one LSTM step for the training pass (training.py: a step of the decoder is one small product and
+// this kernel instead of ten elementwise launches, its backward one kernel instead of twenty).  gates: (B, 4D) pre-activations
+// in PyTorch's order i, f, g, o;  c = f c_prev + i g,  h = o tanh(c).  The activated gates and tanh(c) are kept for the
+// backward pass.
+// ---------------------------------------------------------------------------------------------
+__global__ void lstm_cell_forward_kernel(int32_t B, int32_t D, const float *__restrict__ gates, const float *__restrict__ c_prev,
+                                         float *__restrict__ h, float *__restrict__ c, float *__restrict__ act,
+                                         float *__restrict__ tanh_c) {
+  const int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)B * D) return;
+  const int64_t b = idx / D, u = idx - b * D, g0 = b * 4 * D + u;
+  const float i = sigmoid_f32(gates[g0]), f = sigmoid_f32(gates[g0 + D]), g = tanhf(gates[g0 + 2 * D]),
+              o = sigmoid_f32(gates[g0 + 3 * D]);
+  const float cn = f * c_prev[idx] + i * g, tc = tanhf(cn);
+  c[idx] = cn;
+  h[idx] = o * tc;
+  act[g0] = i;
+  act[g0 + D] = f;
+  act[g0 + 2 * D] = g;
+  act[g0 + 3 * D] = o;
+  tanh_c[idx] = tc;
+}
+
+// dh, dc_next: gradients with respect to the step's outputs h and c (either may be null: zero)
+__global__ void lstm_cell_backward_kernel(int32_t B, int32_t D, const float *__restrict__ act, const float *__restrict__ tanh_c,
+                                          const float *__restrict__ c_prev, const float *__restrict__ dh,
+                                          const float *__restrict__ dc_next, float *__restrict__ dgates,
+                                          float *__restrict__ dc_prev) {
+  const int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)B * D) return;
+  const int64_t b = idx / D, u = idx - b * D, g0 = b * 4 * D + u;
+  const float i = act[g0], f = act[g0 + D], g = act[g0 + 2 * D], o = act[g0 + 3 * D], tc = tanh_c[idx];
+  const float gh = dh ? dh[idx] : 0.f;
+  const float dc = (dc_next ? dc_next[idx] : 0.f) + gh * o * (1.f - tc * tc);
+  dgates[g0] = dc * g * i * (1.f - i);
+  dgates[g0 + D] = dc * c_prev[idx] * f * (1.f - f);
+  dgates[g0 + 2 * D] = dc * i * (1.f - g * g);
+  dgates[g0 + 3 * D] = gh * tc * o * (1.f - o);
+  dc_prev[idx] = dc * f;
+}
+
+// The three figures model_train reports per batch (DNN_tools.py:144-155) from the decoded output and the target, added to
+// running sums: mean square error, 1 - mse / mean((y - mean y)^2), 1 - mse / mean(y^2).  Two launches: partial sums in
+// fp64 (wave reduction, one atomic per wave and quantity), then one thread forms the figures and clears the partial sums.
+__global__ void train_stats_partial_kernel(int64_t n, const float *__restrict__ out, const float *__restrict__ y, double *part) {
+  double se = 0.0, sy = 0.0, syy = 0.0;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const double d = (double)out[i] - (double)y[i], v = (double)y[i];
+    se += d * d;
+    sy += v;
+    syy += v * v;
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    se += __shfl_down(se, off);
+    sy += __shfl_down(sy, off);
+    syy += __shfl_down(syy, off);
+  }
+  // (one atomic per workgroup and quantity, few workgroups: thousands of fp64 atomics on three addresses serialise -
+  // 0.8 ms per call with one per wave of a 600-block grid)
+  __shared__ double w[3][16];
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    w[0][wave] = se;
+    w[1][wave] = sy;
+    w[2][wave] = syy;
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    double t = 0.0;
+    for (int k = 0; k < (int)(blockDim.x >> 6); ++k) t += w[threadIdx.x][k];
+    atomicAdd(&part[threadIdx.x], t);
+  }
+}
+
+__global__ void train_stats_final_kernel(int64_t n, double *part, double *sums) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const double mse = part[0] / (double)n, mean = part[1] / (double)n, msq = part[2] / (double)n;
+  sums[0] += mse;
+  sums[1] += 1.0 - mse / (msq - mean * mean);
+  sums[2] += 1.0 - mse / msq;
+  part[0] = part[1] = part[2] = 0.0;
+}
+
 int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 // How many ways to split K: the candidates are chunk-aligned slice lengths of at least 128; the best one fills whole rounds
@@ -457,6 +541,32 @@ struct Predictor {
         *P2 = nullptr, *Hs = nullptr;
   std::vector<void *> owned;
 };
+
+hipError_t lstm_cell_forward(int32_t B, int32_t D, const float *gates, const float *c_prev, float *h, float *c, float *act,
+                             float *tanh_c, hipStream_t st) {
+  const int64_t n = (int64_t)B * D;
+  if (n > 0)
+    hipLaunchKernelGGL(lstm_cell_forward_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, B, D, gates, c_prev, h, c, act,
+                       tanh_c);
+  return hipGetLastError();
+}
+
+hipError_t lstm_cell_backward(int32_t B, int32_t D, const float *act, const float *tanh_c, const float *c_prev, const float *dh,
+                              const float *dc_next, float *dgates, float *dc_prev, hipStream_t st) {
+  const int64_t n = (int64_t)B * D;
+  if (n > 0)
+    hipLaunchKernelGGL(lstm_cell_backward_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, B, D, act, tanh_c, c_prev, dh,
+                       dc_next, dgates, dc_prev);
+  return hipGetLastError();
+}
+
+hipError_t train_stats(int64_t n, const float *out, const float *y, double *part, double *sums, hipStream_t st) {
+  if (n <= 0) return hipSuccess;
+  const unsigned blocks = (unsigned)std::min<int64_t>((n + 4095) / 4096, 128);
+  hipLaunchKernelGGL(train_stats_partial_kernel, dim3(blocks), dim3(1024), 0, st, n, out, y, part);
+  hipLaunchKernelGGL(train_stats_final_kernel, dim3(1), dim3(64), 0, st, n, part, sums);
+  return hipGetLastError();
+}
 
 const PredictorShape &predictor_shape(const Predictor *p) { return p->sh; }
 int predictor_device(const Predictor *p) { return p->device; }
