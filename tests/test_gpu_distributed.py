@@ -174,6 +174,16 @@ def test_native_rccl_exchange_single_rank(beam_coarse):
     (a, an, ta), (b, bn, tb), (c, cn, tc) = plain.get_state(), synced.get_state(), eager.get_state()
     assert ta == tb == tc  # the host's clock advanced exactly like the device's
     assert rel_l2(b, a) < 1e-13 and rel_l2(bn, an) < 1e-13 and rel_l2(b, c) < 1e-13 and rel_l2(bn, cn) < 1e-13
+    # The library's graphs after many other launches: PyTorch's captured validation graph returned corrupted sums once
+    # ~10^4 kernels had been launched since its capture - these must not.
+    z = torch.zeros(1000, device="cuda")
+    for _ in range(20000):
+        z.add_(1.0)
+    plain.step(201)
+    synced.step_synced(201)  # 67 replays of the graphs instantiated above
+    torch.cuda.synchronize()
+    (a, an, ta), (b, bn, tb) = plain.get_state(), synced.get_state()
+    assert ta == tb and rel_l2(b, a) < 1e-13 and rel_l2(bn, an) < 1e-13 and float(z[0]) == 20000.0
     plain.close()
     synced.close()
     eager.close()
