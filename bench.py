@@ -617,7 +617,7 @@ def main():
     ap.add_argument("--sa-train-epochs", type=int, default=None,
                     help="sync-avoiding leg: epochs of training per rank (0 = the reference's schedule, "
                          "Model_training.py:65); default: as many as fit --sa-train-seconds")
-    ap.add_argument("--sa-train-seconds", type=float, default=60.0,
+    ap.add_argument("--sa-train-seconds", type=float, default=120.0,
                     help="sync-avoiding leg: cap on the training time per rank (further capped by the run's budget)")
     ap.add_argument("--no-rccl-leg", action="store_true",
                     help="N > 1: skip the extra measurement with the RCCL all-reduce when the peer exchange is in use")
