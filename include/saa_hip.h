@@ -324,6 +324,23 @@ int saa_lstm_cell_backward(int32_t device, int32_t batch, int32_t width, const f
                            const float *c_prev_dev, const float *dh_dev, const float *dc_next_dev, float *dgates_dev,
                            float *dc_prev_dev, void *stream);
 
+/* A whole LSTM recurrence of the training pass in one launch, and its backward pass in one launch (`model_train`,
+ * DNN_tools.py:103-165: encoder `nn.LSTM`, DNN_tools.py:32, and the decoder steps, :73-79; widths 50 = the encoder's hidden
+ * size and 100 = the decoder's, Model_training.py:36-40 - other widths are refused and stay with PyTorch):
+ *   gates_t = pre[b, t, :] + h_{t-1} W^T,  c_t = f c_{t-1} + i g,  h_t = o tanh(c_t)   over t = 0..steps-1 (reverse: downwards),
+ * `pre_dev` (batch, steps, 4*width) = input projections + biases, `w_dev` (4*width, width) row-major, `h0_dev` / `c0_dev`
+ * (batch, width) or null = zero.  The forward writes every h_t (`h_all_dev`, batch x steps x width; the last state is its
+ * last processed row) and keeps c_t, the activated gates and tanh(c_t) for the backward, which turns the gradients with
+ * respect to every h_t (`dh_all_dev`) and the final c (`dc_last_dev`, may be null) into those with respect to `pre`, h0 and
+ * c0.  The weight gradient is one product outside: dW = dpre^T . h_prev over all rows and steps. */
+int saa_lstm_recurrence_forward(int32_t device, int32_t batch, int32_t steps, int32_t width, int32_t reverse, const float *pre_dev,
+                                const float *h0_dev, const float *c0_dev, const float *w_dev, float *h_all_dev, float *c_all_dev,
+                                float *act_dev, float *tanh_c_dev, void *stream);
+int saa_lstm_recurrence_backward(int32_t device, int32_t batch, int32_t steps, int32_t width, int32_t reverse,
+                                 const float *dh_all_dev, const float *dc_last_dev, const float *c0_dev, const float *w_dev,
+                                 const float *c_all_dev, const float *act_dev, const float *tanh_c_dev, float *dpre_dev,
+                                 float *dh0_dev, float *dc0_dev, void *stream);
+
 /* The three figures `model_train` / `model_test` accumulate per batch (DNN_tools.py:144-155,196-205) - the mean square error
  * of `out_dev` against `target_dev` (n fp32 elements each), 1 - mse / mean((y - mean y)^2) and 1 - mse / mean(y^2) - added to
  * the three doubles `sums3_dev`; sums in fp64.  `scratch3_dev`: three doubles, zero before the first call, left zero. */

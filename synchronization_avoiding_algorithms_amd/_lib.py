@@ -116,6 +116,8 @@ SIGNATURES = {
     "saa_predictor_destroy": (C.c_int, [_H]),
     "saa_lstm_cell_forward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 7),
     "saa_lstm_cell_backward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 8),
+    "saa_lstm_recurrence_forward": (C.c_int, [C.c_int32] * 5 + [C.c_void_p] * 9),
+    "saa_lstm_recurrence_backward": (C.c_int, [C.c_int32] * 5 + [C.c_void_p] * 11),
     "saa_train_stats": (C.c_int, [C.c_int32, C.c_int64] + [C.c_void_p] * 5),
     "saa_topology_build": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _ip, _ip, C.c_int32, C.c_int32, _dp, C.c_int32, _ip,
                                      C.c_double, C.POINTER(_H)]),

@@ -1634,6 +1634,32 @@ int saa_lstm_cell_backward(int32_t device, int32_t batch, int32_t width, const f
   return SAA_OK;
 }
 
+int saa_lstm_recurrence_forward(int32_t device, int32_t batch, int32_t steps, int32_t width, int32_t reverse, const float *pre_dev,
+                                const float *h0_dev, const float *c0_dev, const float *w_dev, float *h_all_dev, float *c_all_dev,
+                                float *act_dev, float *tanh_c_dev, void *stream) {
+  if (batch < 0 || steps < 0 || (batch > 0 && steps > 0 && (!pre_dev || !w_dev || !h_all_dev || !c_all_dev || !act_dev || !tanh_c_dev)))
+    return fail(SAA_E_ARG, "saa_lstm_recurrence_forward: bad argument");
+  if (width != 50 && width != 100) return fail(SAA_E_ARG, "saa_lstm_recurrence_forward: width must be 50 or 100");
+  HIP_TRY(hipSetDevice(device));
+  HIP_TRY(saa::lstm_rec_forward(batch, steps, width, reverse, pre_dev, h0_dev, c0_dev, w_dev, h_all_dev, c_all_dev, act_dev,
+                                tanh_c_dev, static_cast<hipStream_t>(stream)));
+  return SAA_OK;
+}
+
+int saa_lstm_recurrence_backward(int32_t device, int32_t batch, int32_t steps, int32_t width, int32_t reverse,
+                                 const float *dh_all_dev, const float *dc_last_dev, const float *c0_dev, const float *w_dev,
+                                 const float *c_all_dev, const float *act_dev, const float *tanh_c_dev, float *dpre_dev,
+                                 float *dh0_dev, float *dc0_dev, void *stream) {
+  if (batch < 0 || steps < 0 ||
+      (batch > 0 && steps > 0 && (!dh_all_dev || !w_dev || !c_all_dev || !act_dev || !tanh_c_dev || !dpre_dev || !dh0_dev || !dc0_dev)))
+    return fail(SAA_E_ARG, "saa_lstm_recurrence_backward: bad argument");
+  if (width != 50 && width != 100) return fail(SAA_E_ARG, "saa_lstm_recurrence_backward: width must be 50 or 100");
+  HIP_TRY(hipSetDevice(device));
+  HIP_TRY(saa::lstm_rec_backward(batch, steps, width, reverse, dh_all_dev, dc_last_dev, c0_dev, w_dev, c_all_dev, act_dev,
+                                 tanh_c_dev, dpre_dev, dh0_dev, dc0_dev, static_cast<hipStream_t>(stream)));
+  return SAA_OK;
+}
+
 int saa_train_stats(int32_t device, int64_t n, const float *out_dev, const float *target_dev, double *scratch3_dev,
                     double *sums3_dev, void *stream) {
   if (n < 0 || (n > 0 && (!out_dev || !target_dev || !scratch3_dev || !sums3_dev)))

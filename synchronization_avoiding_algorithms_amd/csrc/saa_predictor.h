@@ -38,6 +38,14 @@ hipError_t lstm_cell_forward(int32_t B, int32_t D, const float *gates, const flo
 hipError_t lstm_cell_backward(int32_t B, int32_t D, const float *act, const float *tanh_c, const float *c_prev, const float *dh,
                               const float *dc_next, float *dgates, float *dc_prev, hipStream_t st);
 
+// A whole LSTM recurrence of the training pass and its backward, one launch each (width 50 or 100; else
+// hipErrorInvalidValue): see saa_hip.h.
+hipError_t lstm_rec_forward(int32_t B, int32_t T, int32_t HP, int32_t reverse, const float *pre, const float *h0, const float *c0,
+                            const float *W, float *H, float *c_all, float *act, float *tanhc, hipStream_t st);
+hipError_t lstm_rec_backward(int32_t B, int32_t T, int32_t HP, int32_t reverse, const float *dH, const float *dcT, const float *c0,
+                             const float *W, const float *c_all, const float *act, const float *tanhc, float *dpre, float *dh0,
+                             float *dc0, hipStream_t st);
+
 // sums[0..2] += (mse, 1 - mse / var(y), 1 - mse / mean(y^2)) of `out` against `y` (n fp32 elements each); `part` = three
 // doubles of scratch that are zero on entry and left zero.
 hipError_t train_stats(int64_t n, const float *out, const float *y, double *part, double *sums, hipStream_t st);

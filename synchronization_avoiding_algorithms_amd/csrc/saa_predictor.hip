@@ -467,6 +467,132 @@ __global__ void lstm_cell_backward_kernel(int32_t B, int32_t D, const float *__r
   dc_prev[idx] = dc * f;
 }
 
+// ---------------------------------------------------------------------------------------------
+// A whole LSTM recurrence of the TRAINING pass in one launch, and its backward pass in one launch (training.py: the encoder's
+// four (layer, direction) recurrences through MIOpen cost a product and a pointwise kernel per time step and pass, the
+// decoder's twenty steps two kernels forward and seven backward each - 570 of the 690 launches of an optimiser step).
+//   gates_t = pre[b, t, :] + h_{t-1} W^T     (pre: input projections + biases, formed by one product outside)
+//   i, f, g, o = s(.), s(.), tanh(.), s(.);   c_t = f c_{t-1} + i g;   h_t = o tanh(c_t)          (PyTorch's gate order)
+// over t = 0..T-1 (reverse: T-1..0), one workgroup per batch row, thread r < 4H' one gate row with its H' weights in
+// registers (H' at compile time: 50 for the encoder, 100 for the decoder).  The forward keeps the activated gates, tanh(c_t)
+// and c_t for the backward, which walks the steps in the opposite order: per step the cell's backward (thread u < H'), then
+// dh_{t-1} += dgates_t W as four partial sums per unit (thread (gate kind k, u) holds W[k H' + j][u], j < H').  The weight
+// gradient is ONE product over all rows and steps afterwards (dpre^T . h_prev), outside.
+// ---------------------------------------------------------------------------------------------
+struct RecArgs {
+  int B, T, reverse;
+  const float *pre;   // (B, T, 4H')
+  const float *h0, *c0;  // (B, H') or null = zero
+  const float *W;     // (4H', H') row-major
+  float *H;           // (B, T, H')
+  float *c_all;       // (B, T, H')
+  float *act;         // (B, T, 4H')
+  float *tanhc;       // (B, T, H')
+};
+
+template <int HP>
+__global__ void __launch_bounds__((4 * HP + 63) / 64 * 64) lstm_rec_forward_kernel(RecArgs a) {
+  __shared__ __attribute__((aligned(16))) float hbuf[HP], gates[4 * HP];
+  const int tid = threadIdx.x, b = blockIdx.x, G = 4 * HP;
+  const bool gate_thread = tid < G, unit_thread = tid < HP;
+  const int g = min(tid, G - 1);
+  float w[HP];
+  col_load<HP>(w, a.W, g * HP, 1);
+  const bool is_tanh = g >= 2 * HP && g < 3 * HP;
+  float c = (unit_thread && a.c0) ? a.c0[(int64_t)b * HP + tid] : 0.f;
+  if (unit_thread) hbuf[tid] = a.h0 ? a.h0[(int64_t)b * HP + tid] : 0.f;
+  __syncthreads();
+  float pv = a.pre[((int64_t)b * a.T + (a.reverse ? a.T - 1 : 0)) * G + g];
+  for (int s = 0; s < a.T; ++s) {
+    const int t = a.reverse ? a.T - 1 - s : s, tn = a.reverse ? max(t - 1, 0) : min(t + 1, a.T - 1);
+    const int64_t row = (int64_t)b * a.T + t;
+    const float nxt = a.pre[((int64_t)b * a.T + tn) * G + g];  // requested a step ahead
+    const float v = col_dot<HP>(w, a.W, g * HP, 1, hbuf, HP, pv);
+    pv = nxt;
+    const float sg = sigmoid_f32(is_tanh ? 2.0f * v : v), av = is_tanh ? 2.0f * sg - 1.0f : sg;
+    if (gate_thread) {
+      gates[g] = av;
+      a.act[row * G + g] = av;
+    }
+    __syncthreads();
+    if (unit_thread) {
+      c = gates[HP + tid] * c + gates[tid] * gates[2 * HP + tid];
+      const float tc = tanhf(c), hv = gates[3 * HP + tid] * tc;
+      hbuf[tid] = hv;
+      a.H[row * HP + tid] = hv;
+      a.c_all[row * HP + tid] = c;
+      a.tanhc[row * HP + tid] = tc;
+    }
+    __syncthreads();
+  }
+}
+
+struct RecBwdArgs {
+  int B, T, reverse;
+  const float *dH;     // (B, T, H') gradient with respect to every h_t (the caller's slices and sums included)
+  const float *dcT;    // (B, H') gradient with respect to the final cell state, or null
+  const float *c0;     // (B, H') or null
+  const float *W;      // (4H', H')
+  const float *c_all, *act, *tanhc;
+  float *dpre;         // (B, T, 4H')
+  float *dh0, *dc0;    // (B, H')
+};
+
+template <int HP>
+__global__ void __launch_bounds__((4 * HP + 63) / 64 * 64) lstm_rec_backward_kernel(RecBwdArgs a) {
+  __shared__ __attribute__((aligned(16))) float dg[4 * HP], part[4][HP];
+  const int tid = threadIdx.x, b = blockIdx.x, G = 4 * HP;
+  const bool gate_thread = tid < G, unit_thread = tid < HP;
+  const int gt = min(tid, G - 1), kind = gt / HP, u = gt - kind * HP;
+  float w[HP];  // W[kind*HP + j][u], j < HP
+  col_load<HP>(w, a.W, kind * HP * HP + u, HP);
+  float dh_rec = 0.f, dc = (unit_thread && a.dcT) ? a.dcT[(int64_t)b * HP + tid] : 0.f;
+  const int ut = min(tid, HP - 1);
+  // what a step reads, requested a step ahead (seven dependent round trips per step otherwise)
+  float i, f, gg, o, tc, cp, dh;
+  auto fetch = [&](int s) {
+    const int t = a.reverse ? a.T - 1 - s : s, t_prev = a.reverse ? t + 1 : t - 1;
+    const int64_t row = (int64_t)b * a.T + t;
+    i = a.act[row * G + ut];
+    f = a.act[row * G + HP + ut];
+    gg = a.act[row * G + 2 * HP + ut];
+    o = a.act[row * G + 3 * HP + ut];
+    tc = a.tanhc[row * HP + ut];
+    dh = a.dH[row * HP + ut];
+    cp = s > 0 ? a.c_all[((int64_t)b * a.T + t_prev) * HP + ut] : (a.c0 ? a.c0[(int64_t)b * HP + ut] : 0.f);
+  };
+  fetch(a.T - 1);
+  for (int s = a.T - 1; s >= 0; --s) {  // the forward's steps, last one first
+    const int t = a.reverse ? a.T - 1 - s : s;
+    const int64_t row = (int64_t)b * a.T + t;
+    if (unit_thread) {
+      const float gh = dh + dh_rec;
+      dc += gh * o * (1.f - tc * tc);
+      const float di = dc * gg * i * (1.f - i), df = dc * cp * f * (1.f - f), dgg = dc * i * (1.f - gg * gg),
+                  dout = gh * tc * o * (1.f - o);
+      dg[tid] = di;
+      dg[HP + tid] = df;
+      dg[2 * HP + tid] = dgg;
+      dg[3 * HP + tid] = dout;
+      a.dpre[row * G + tid] = di;
+      a.dpre[row * G + HP + tid] = df;
+      a.dpre[row * G + 2 * HP + tid] = dgg;
+      a.dpre[row * G + 3 * HP + tid] = dout;
+      dc *= f;
+    }
+    if (s > 0) fetch(s - 1);
+    __syncthreads();
+    const float p = col_dot<HP>(w, a.W, kind * HP * HP + u, HP, dg + kind * HP, HP, 0.f);
+    if (gate_thread) part[kind][u] = p;
+    __syncthreads();
+    if (unit_thread) dh_rec = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
+  }
+  if (unit_thread) {
+    a.dh0[(int64_t)b * HP + tid] = dh_rec;
+    a.dc0[(int64_t)b * HP + tid] = dc;
+  }
+}
+
 // The three figures model_train reports per batch (DNN_tools.py:144-155) from the decoded output and the target, added to
 // running sums: mean square error, 1 - mse / mean((y - mean y)^2), 1 - mse / mean(y^2).  Two launches: partial sums in
 // fp64 (wave reduction, one atomic per wave and quantity), then one thread forms the figures and clears the partial sums.
@@ -557,6 +683,33 @@ hipError_t lstm_cell_backward(int32_t B, int32_t D, const float *act, const floa
   if (n > 0)
     hipLaunchKernelGGL(lstm_cell_backward_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, B, D, act, tanh_c, c_prev, dh,
                        dc_next, dgates, dc_prev);
+  return hipGetLastError();
+}
+
+hipError_t lstm_rec_forward(int32_t B, int32_t T, int32_t HP, int32_t reverse, const float *pre, const float *h0, const float *c0,
+                            const float *W, float *H, float *c_all, float *act, float *tanhc, hipStream_t st) {
+  if (B <= 0 || T <= 0) return hipSuccess;
+  const RecArgs a{B, T, reverse, pre, h0, c0, W, H, c_all, act, tanhc};
+  if (HP == 50)
+    hipLaunchKernelGGL(lstm_rec_forward_kernel<50>, dim3(B), dim3(256), 0, st, a);
+  else if (HP == 100)
+    hipLaunchKernelGGL(lstm_rec_forward_kernel<100>, dim3(B), dim3(448), 0, st, a);
+  else
+    return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
+hipError_t lstm_rec_backward(int32_t B, int32_t T, int32_t HP, int32_t reverse, const float *dH, const float *dcT, const float *c0,
+                             const float *W, const float *c_all, const float *act, const float *tanhc, float *dpre, float *dh0,
+                             float *dc0, hipStream_t st) {
+  if (B <= 0 || T <= 0) return hipSuccess;
+  const RecBwdArgs a{B, T, reverse, dH, dcT, c0, W, c_all, act, tanhc, dpre, dh0, dc0};
+  if (HP == 50)
+    hipLaunchKernelGGL(lstm_rec_backward_kernel<50>, dim3(B), dim3(256), 0, st, a);
+  else if (HP == 100)
+    hipLaunchKernelGGL(lstm_rec_backward_kernel<100>, dim3(B), dim3(448), 0, st, a);
+  else
+    return hipErrorInvalidValue;
   return hipGetLastError();
 }
 

@@ -93,6 +93,91 @@ class _FusedCell(torch.autograd.Function):
         return dgates, dc_prev
 
 
+_FUSED_RECURRENCE = __import__("os").environ.get("SAA_TRAIN_FUSED_RECURRENCE", "1") != "0"
+
+
+class _Recurrence(torch.autograd.Function):
+    """``h_t, c_t`` over all time steps of one LSTM recurrence (``gates_t = pre_t + h_{t-1} W^T``) in ONE launch of the
+    library (``saa_lstm_recurrence_forward``), its backward in one more plus one product for the weight gradient -
+    where the step-by-step formulation costs two launches per step forward and seven backward (decoder) or four per step,
+    layer, direction and pass (MIOpen's encoder).  Widths 50 and 100."""
+
+    @staticmethod
+    def forward(ctx, pre, h0, c0, W, reverse):
+        from . import _lib
+
+        lib = _lib.load()
+        pre, W = pre.contiguous(), W.contiguous()
+        B, T, G = pre.shape
+        H = G // 4
+        h0c = h0.contiguous() if h0 is not None else None
+        c0c = c0.contiguous() if c0 is not None else None
+        Hall = torch.empty((B, T, H), dtype=pre.dtype, device=pre.device)
+        c_all, tanhc, act = torch.empty_like(Hall), torch.empty_like(Hall), torch.empty_like(pre)
+        stream = torch.cuda.current_stream(pre.device).cuda_stream
+        _lib.check(lib.saa_lstm_recurrence_forward(pre.device.index, B, T, H, int(bool(reverse)), pre.data_ptr(),
+                                                   h0c.data_ptr() if h0c is not None else None,
+                                                   c0c.data_ptr() if c0c is not None else None, W.data_ptr(),
+                                                   Hall.data_ptr(), c_all.data_ptr(), act.data_ptr(), tanhc.data_ptr(), stream))
+        ctx.save_for_backward(Hall, c_all, act, tanhc, W, h0c if h0c is not None else torch.empty(0, device=pre.device),
+                              c0c if c0c is not None else torch.empty(0, device=pre.device))
+        ctx.reverse, ctx.has_h0, ctx.has_c0 = bool(reverse), h0c is not None, c0c is not None
+        last = 0 if reverse else T - 1
+        return Hall, c_all[:, last, :].clone()
+
+    @staticmethod
+    def backward(ctx, dH, dcT):
+        from . import _lib
+
+        lib = _lib.load()
+        Hall, c_all, act, tanhc, W, h0, c0 = ctx.saved_tensors
+        B, T, H = Hall.shape
+        dH = dH.contiguous() if dH is not None else torch.zeros_like(Hall)
+        dcT = dcT.contiguous() if dcT is not None else None
+        dpre, dh0, dc0 = torch.empty_like(act), torch.empty((B, H), dtype=Hall.dtype, device=Hall.device), \
+            torch.empty((B, H), dtype=Hall.dtype, device=Hall.device)
+        stream = torch.cuda.current_stream(Hall.device).cuda_stream
+        _lib.check(lib.saa_lstm_recurrence_backward(Hall.device.index, B, T, H, int(ctx.reverse), dH.data_ptr(),
+                                                    dcT.data_ptr() if dcT is not None else None,
+                                                    c0.data_ptr() if ctx.has_c0 else None, W.data_ptr(), c_all.data_ptr(),
+                                                    act.data_ptr(), tanhc.data_ptr(), dpre.data_ptr(), dh0.data_ptr(),
+                                                    dc0.data_ptr(), stream))
+        # h_{t-1} of every step in processing order: the initial state, then the outputs shifted by one step
+        first = h0.unsqueeze(1) if ctx.has_h0 else torch.zeros((B, 1, H), dtype=Hall.dtype, device=Hall.device)
+        hprev = torch.cat((Hall[:, 1:, :], first), dim=1) if ctx.reverse else torch.cat((first, Hall[:, :-1, :]), dim=1)
+        dW = dpre.reshape(B * T, 4 * H).t() @ hprev.reshape(B * T, H)
+        return dpre, (dh0 if ctx.has_h0 else None), (dc0 if ctx.has_c0 else None), dW, None
+
+
+def _recurrence_ok(t, width):
+    return _FUSED_RECURRENCE and t.is_cuda and t.dtype == torch.float32 and width in (50, 100)
+
+
+def _encode_fused(model, X):
+    """``LSTM_Encoder.forward`` (``DNN_tools.py:35-59``) with every (layer, direction) recurrence as one launch
+    (:class:`_Recurrence`): per layer and direction one product for the input projections of all time steps, the recurrence,
+    and the layer's output as the concatenation of the two directions; returns the last layer's final forward | backward
+    states like the module does."""
+    enc = model.encoder
+    lstm, H, L, dirs = enc.lstm_encoder, enc.hidden_size, enc.num_layers, enc.D
+    B, T = X.shape[0], X.shape[1]
+    inp = X
+    for layer in range(L):
+        outs, finals = [], []
+        for d in range(dirs):
+            sfx = f"_l{layer}" + ("_reverse" if d else "")
+            w_ih, w_hh = getattr(lstm, "weight_ih" + sfx), getattr(lstm, "weight_hh" + sfx)
+            bias = getattr(lstm, "bias_ih" + sfx) + getattr(lstm, "bias_hh" + sfx)
+            pre = torch.addmm(bias, inp.reshape(B * T, -1), w_ih.t()).reshape(B, T, 4 * H)
+            Hall, cT = _Recurrence.apply(pre, None, None, w_hh, bool(d))
+            outs.append(Hall)
+            finals.append((Hall[:, 0 if d else T - 1, :], cT))
+        inp = torch.cat(outs, dim=2) if dirs == 2 else outs[0]
+    if dirs == 2:
+        return (torch.cat((finals[0][0], finals[1][0]), 1).unsqueeze(0), torch.cat((finals[0][1], finals[1][1]), 1).unsqueeze(0))
+    return finals[0][0].unsqueeze(0), finals[0][1].unsqueeze(0)
+
+
 def _cell(gates, c):
     """``c' = f c + i g``, ``h = o tanh(c')`` from the pre-activations ``(B, 4D)`` in PyTorch's gate order."""
     if gates.is_cuda and _FUSED_CELL and gates.dtype == torch.float32:
@@ -110,13 +195,25 @@ def _decode_folded(model, X, n_future):
     an I -> 4D one plus an ``nn.LSTM`` call; the outputs of all steps come from one product at the end.  Autograd
     differentiates through the fold, so the gradients with respect to ``W_ih``, ``W_fc``, ``W_hh`` and the biases are those
     of the literal form up to fp32 round-off (what predictor kernels do for inference, ``csrc/saa_predictor.hip``)."""
-    h, c = model.encoder(X)
+    enc = model.encoder
+    if _recurrence_ok(X, enc.hidden_size) and enc.lstm_encoder.dropout == 0.0:
+        h, c = _encode_fused(model, X)
+    else:
+        h, c = model.encoder(X)
     h, c = h[0], c[0]
     lstm, fc = model.decoder.lstm_decoder, model.decoder.fc
     w_ih, w_hh, bias = lstm.weight_ih_l0, lstm.weight_hh_l0, lstm.bias_ih_l0 + lstm.bias_hh_l0
     w_comb = torch.addmm(w_hh, w_ih, fc.weight)                       # (4D, D)
     b_comb = torch.addmv(bias, w_ih, fc.bias)
     gates = torch.addmm(bias, X[:, -1, :], w_ih.t()) + h @ w_hh.t()   # first step: the last history row (:224)
+    if _recurrence_ok(X, model.decoder.hidden_size):
+        # all steps in one launch: the first step's pre-activations as they stand, the bias of the folded form for the
+        # others; the recurrent matrix of the kernel is the folded one, and its initial h is zero (h's part of the first
+        # step is already inside `gates`)
+        B = X.shape[0]
+        pre = torch.cat((gates.unsqueeze(1), b_comb.expand(B, n_future - 1, -1)), dim=1) if n_future > 1 else gates.unsqueeze(1)
+        H, _ = _Recurrence.apply(pre, None, c, w_comb, False)
+        return torch.matmul(H, fc.weight.t()) + fc.bias
     hs = []
     for t in range(n_future):
         if t > 0:
