@@ -427,7 +427,8 @@ def fit_windows(X, Y, hidden_size=50, batch_size=10, learning_rate=5e-4, decay=0
     criterion = nn.MSELoss()
     use_graph = device.type == "cuda" and os.environ.get("SAA_TRAIN_GRAPH", "1") != "0"
     if use_graph:  # capturable Adam with a tensor learning rate: the scheduler's updates reach the graph replays
-        optimizer = torch.optim.Adam(model.parameters(), lr=torch.tensor(learning_rate, device=device), capturable=True)
+        optimizer = torch.optim.Adam(model.parameters(), lr=torch.tensor(learning_rate, device=device), capturable=True,
+                                     fused=os.environ.get("SAA_TRAIN_FUSED_ADAM", "1") != "0")  # one kernel, one pass over the parameters
     else:
         optimizer = torch.optim.Adam(model.parameters(), lr=learning_rate)
     scheduler = torch.optim.lr_scheduler.LambdaLR(optimizer, lr_lambda=lambda epoch: decay ** epoch)
