@@ -113,6 +113,25 @@ def test_config4_shape_against_the_fp64_evaluation_and_pytorch_rocm():
         assert torch.equal(got, nat.predict(n, hist, smax, smin))  # deterministic: fixed summation orders
 
 
+def test_strided_history_and_table():
+    """The history as a column block of a wider device matrix (row stride > input_size, rows not 16-byte aligned) and the
+    table written into a wider one: what lies outside the block is neither read nor touched."""
+    torch.manual_seed(5)
+    I, H, n_p, n_f, n_s = 37, 50, 6, 5, 12
+    model = pr.LSTM_encoder_decoder(I, H).cuda().eval()
+    wide = torch.full((n_p * n_s + 9, I + 5), float("nan"), dtype=torch.float64, device="cuda")
+    hist = wide[:, 3:3 + I]
+    hist.copy_(torch.cumsum(torch.randn(wide.shape[0], I, dtype=torch.float64, device="cuda") * 1e-4, 0))
+    smax, smin = float(hist.max()) * 1.1, float(hist.min()) * 1.1
+    nat = pr.NativePredictor(model, n_p, n_f, n_s)
+    n = wide.shape[0] - 2
+    want = nat.predict(n, hist.contiguous(), smax, smin)
+    out_wide = torch.full((n_s * n_f, I + 7), -7.0, dtype=torch.float64, device="cuda")
+    got = nat.predict(n, hist, smax, smin, out_wide[:, 2:2 + I])
+    assert torch.equal(got, want) and torch.isfinite(want).all()
+    assert float((out_wide[:, :2] + 7.0).abs().max()) == 0.0 and float((out_wide[:, 2 + I:] + 7.0).abs().max()) == 0.0
+
+
 def test_arguments_are_checked():
     torch.manual_seed(0)
     model = pr.LSTM_encoder_decoder(6, 4).cuda().eval()
