@@ -245,8 +245,9 @@ class GraphedTrainStep:
 
     def _step(self):
         self.optimizer.zero_grad(set_to_none=True)
-        self.out = _decode(self.model, self.X, self.n_future)  # (static inside the captured graph: read by _stats)
-        loss = self.criterion(self.out, self.Y)
+        out = _decode(self.model, self.X, self.n_future)
+        self.out = out.detach()  # (same storage, static inside the captured graph: read by _stats; no hold on the autograd graph)
+        loss = self.criterion(out, self.Y)
         loss.backward()
         self.optimizer.step()
 

@@ -40,5 +40,5 @@ with torch.no_grad():
     per = (time.time() - t0) / 10
 truth = hist[start:start + n_f * n_s]
 err = float((table - truth).norm() / truth.norm())
-print(f"predictor: {per * 1e3:.2f} ms per window of {n_f * n_s} steps (graph replay), rel-L2 of the predicted window "
+print(f"predictor: {per * 1e3:.2f} ms per window of {n_f * n_s} steps ({predictor.backend}), rel-L2 of the predicted window "
       f"against the history it was trained on {err:.3e}")
