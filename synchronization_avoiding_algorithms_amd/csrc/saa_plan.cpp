@@ -792,6 +792,282 @@ bool build_once(int32_t n_nodes, int32_t n_elems, const double *xyz, const int32
       for (int32_t i = 0; i < n_nodes; ++i)
         weight[i] = std::max<int64_t>(1, static_cast<int64_t>(weight[i] * (copies[owner[i]] / mean)));
     }
+    // ---- chunk repair (one block per CU, 1024-thread workgroups: see first_round_cap below) ---------------------------
+    // A block's items run as 1024 in the first round + 64-item chunks in the second phase, dealt to 16 waves on four SIMDs:
+    // a block one chunk over the others gives one SIMD 11 chunks instead of 10, and the blocks wait for each other.  The
+    // re-weighted bisection leaves the copies within +-2 % of their mean, a handful of blocks a few items over the chunk
+    // count the mean fits.  Those hand nodes to the sibling leaf of their last bisection - the cut between the two moves,
+    // a strip of the plane it runs through changes sides - as long as the sibling stays inside the budget itself.
+    const char *rep_env = getenv("SAA_PLAN_CHUNK_REPAIR");
+    const int32_t nblk = static_cast<int32_t>(block_start.size());
+    if (!(rep_env && rep_env[0] == '0') && nblk <= 256 && nblk >= 2 && (nblk & (nblk - 1)) == 0) {
+      auto leaf_end = [&](int32_t b) { return b + 1 < nblk ? block_start[b + 1] : n_nodes; };
+      for (int32_t b = 0; b < nblk; ++b)
+        for (int32_t i = block_start[b]; i < leaf_end(b); ++i) owner[plan.new_to_old[i]] = b;
+      auto count_copies = [&](std::vector<int32_t> &out) {
+        out.assign(nblk, 0);
+        for (int32_t e = 0; e < n_elems; ++e) {
+          int32_t bs[4];
+          int cnt = 0;
+          for (int a = 0; a < 4; ++a) {
+            const int32_t bb = owner[tets[4 * static_cast<int64_t>(e) + a]];
+            bool seen = false;
+            for (int j = 0; j < cnt; ++j) seen |= (bs[j] == bb);
+            if (!seen) bs[cnt++] = bb;
+          }
+          for (int j = 0; j < cnt; ++j) ++out[bs[j]];
+        }
+        if (extra_work)
+          for (int32_t i = 0; i < n_nodes; ++i) out[owner[i]] += extra_work[i];
+      };
+      count_copies(copies);
+      double mean = 0;
+      int32_t mx = 0;
+      for (int32_t c : copies) {
+        mean += c;
+        mx = std::max(mx, c);
+      }
+      mean /= nblk;
+      if (mx >= 4096) {  // (what pick_threads answers with 1024 threads)
+        // items ~ copies / 2 + a few single elements and idle slots; the chunk count the mean fits with 0.4 % to spare
+        const double mean_items = 0.5 * mean + 6.0;
+        const int32_t chunks = static_cast<int32_t>(std::ceil((1.004 * mean_items - 1024.0) / 64.0));
+        const int32_t budget = 2 * (1024 + 64 * std::max(chunks, 0) - 8);
+        // node -> elements
+        std::vector<int64_t> adj_off(static_cast<size_t>(n_nodes) + 1, 0);
+        for (int64_t i = 0; i < 4 * static_cast<int64_t>(n_elems); ++i) ++adj_off[tets[i] + 1];
+        for (int32_t i = 0; i < n_nodes; ++i) adj_off[i + 1] += adj_off[i];
+        std::vector<int32_t> adj(adj_off[n_nodes]);
+        {
+          std::vector<int64_t> cur(adj_off.begin(), adj_off.end() - 1);
+          for (int32_t e = 0; e < n_elems; ++e)
+            for (int a = 0; a < 4; ++a) adj[cur[tets[4 * static_cast<int64_t>(e) + a]]++] = e;
+        }
+        std::vector<char> mark(n_elems, 0);
+        std::vector<int32_t> touched;
+        int32_t repaired = 0, failed = 0;
+        for (int32_t b = 0; b + 1 < nblk; b += 2) {
+          if (copies[b] <= budget && copies[b + 1] <= budget) continue;
+          const int32_t heavy = copies[b] >= copies[b + 1] ? b : b + 1, light = heavy ^ 1;
+          if (copies[light] >= budget) {
+            ++failed;
+            continue;
+          }
+          const int32_t s0 = block_start[b], s2 = leaf_end(b + 1);
+          int32_t k = block_start[b + 1] - s0;
+          // the order of the bisection that made the two leaves: along the longest axis of the pair, ties by node id
+          double mn[3] = {1e300, 1e300, 1e300}, mxx[3] = {-1e300, -1e300, -1e300};
+          for (int32_t i = s0; i < s2; ++i)
+            for (int a = 0; a < 3; ++a) {
+              const double v = xyz[3 * static_cast<int64_t>(plan.new_to_old[i]) + a];
+              mn[a] = std::min(mn[a], v);
+              mxx[a] = std::max(mxx[a], v);
+            }
+          int ax = 0;
+          for (int a = 1; a < 3; ++a)
+            if (mxx[a] - mn[a] > mxx[ax] - mn[ax]) ax = a;
+          std::sort(plan.new_to_old.begin() + s0, plan.new_to_old.begin() + s2, [&](int32_t p, int32_t q) {
+            const double vp = xyz[3 * static_cast<int64_t>(p) + ax], vq = xyz[3 * static_cast<int64_t>(q) + ax];
+            return vp < vq || (vp == vq && p < q);
+          });
+          // elements touching the pair
+          touched.clear();
+          for (int32_t i = s0; i < s2; ++i)
+            for (int64_t j = adj_off[plan.new_to_old[i]]; j < adj_off[plan.new_to_old[i] + 1]; ++j)
+              if (!mark[adj[j]]) {
+                mark[adj[j]] = 1;
+                touched.push_back(adj[j]);
+              }
+          for (int32_t e : touched) mark[e] = 0;
+          const int32_t other = copies[b] + copies[b + 1];  // (for the extra work of nodes that change sides)
+          (void)other;
+          auto pair_copies = [&](int32_t kk, int32_t &cl, int32_t &cr) {
+            for (int32_t i = s0; i < s2; ++i) owner[plan.new_to_old[i]] = i - s0 < kk ? b : b + 1;
+            cl = cr = 0;
+            for (int32_t e : touched) {
+              bool l = false, r = false;
+              for (int a = 0; a < 4; ++a) {
+                const int32_t o = owner[tets[4 * static_cast<int64_t>(e) + a]];
+                l |= o == b;
+                r |= o == b + 1;
+              }
+              cl += l;
+              cr += r;
+            }
+            if (extra_work)
+              for (int32_t i = s0; i < s2; ++i) (i - s0 < kk ? cl : cr) += extra_work[plan.new_to_old[i]];
+          };
+          const int32_t dir = heavy == b ? -1 : +1, k0 = k, limit = std::max<int32_t>(8, (heavy == b ? k : (s2 - s0 - k)) / 8);
+          int32_t cl = 0, cr = 0, best_k = k;
+          bool ok = false;
+          for (int32_t moved = 2; moved <= limit; moved += 2) {
+            const int32_t kk = k0 + dir * moved;
+            if (kk < 1 || kk > s2 - s0 - 1) break;
+            pair_copies(kk, cl, cr);
+            const int32_t ch = heavy == b ? cl : cr, cli = heavy == b ? cr : cl;
+            if (cli > budget) break;
+            best_k = kk;
+            if (ch <= budget) {
+              ok = true;
+              break;
+            }
+          }
+          k = ok ? best_k : k0;
+          pair_copies(k, cl, cr);
+          copies[b] = cl;
+          copies[b + 1] = cr;
+          ok ? ++repaired : ++failed;
+          if (getenv("SAA_PLAN_DEBUG"))
+            fprintf(stderr, "plan:   pair %d/%d: %s, cut moved by %d nodes, copies now %d / %d (last trial %d / %d)\n", b, b + 1,
+                    ok ? "repaired" : "not repaired", std::abs(k - k0), copies[b], copies[b + 1], cl, cr);
+          // the two leaves in their block-local order again
+          auto lex = [&](int32_t p, int32_t q) {
+            const double *pa = xyz + 3 * static_cast<int64_t>(p), *pb = xyz + 3 * static_cast<int64_t>(q);
+            if (pa[0] != pb[0]) return pa[0] < pb[0];
+            if (pa[1] != pb[1]) return pa[1] < pb[1];
+            if (pa[2] != pb[2]) return pa[2] < pb[2];
+            return p < q;
+          };
+          std::sort(plan.new_to_old.begin() + s0, plan.new_to_old.begin() + s0 + k, lex);
+          std::sort(plan.new_to_old.begin() + s0 + k, plan.new_to_old.begin() + s2, lex);
+          block_start[b + 1] = s0 + k;
+        }
+        // Pairs that cannot settle it between themselves (a strip that changes sides brings its new owner more copies
+        // than it takes from the old one): the cut ONE level up moves instead, between the pair and the pair next to it,
+        // and both pairs are bisected again by weight.
+        int32_t repaired4 = 0;
+        if (nblk >= 4) {
+          auto axis_of = [&](int32_t lo, int32_t hi) {
+            double mn[3] = {1e300, 1e300, 1e300}, mxx[3] = {-1e300, -1e300, -1e300};
+            for (int32_t i = lo; i < hi; ++i)
+              for (int a = 0; a < 3; ++a) {
+                const double v = xyz[3 * static_cast<int64_t>(plan.new_to_old[i]) + a];
+                mn[a] = std::min(mn[a], v);
+                mxx[a] = std::max(mxx[a], v);
+              }
+            int ax = 0;
+            for (int a = 1; a < 3; ++a)
+              if (mxx[a] - mn[a] > mxx[ax] - mn[ax]) ax = a;
+            return ax;
+          };
+          auto sort_axis = [&](int32_t lo, int32_t hi, int ax) {
+            std::sort(plan.new_to_old.begin() + lo, plan.new_to_old.begin() + hi, [&](int32_t p, int32_t q) {
+              const double vp = xyz[3 * static_cast<int64_t>(p) + ax], vq = xyz[3 * static_cast<int64_t>(q) + ax];
+              return vp < vq || (vp == vq && p < q);
+            });
+          };
+          auto weighted_mid = [&](int32_t lo, int32_t hi) {  // Rcb::split for two leaves
+            int64_t total = 0;
+            for (int32_t i = lo; i < hi; ++i) total += weight[plan.new_to_old[i]];
+            const int64_t want = (total + 1) / 2;
+            int64_t acc = 0;
+            int32_t kk = 0;
+            const int32_t n = hi - lo;
+            while (kk < n - 1 && acc + weight[plan.new_to_old[lo + kk]] / 2 < want) acc += weight[plan.new_to_old[lo + kk++]];
+            return std::max(1, std::min(n - 1, kk));
+          };
+          auto lex_sort = [&](int32_t lo, int32_t hi) {
+            std::sort(plan.new_to_old.begin() + lo, plan.new_to_old.begin() + hi, [&](int32_t p, int32_t q) {
+              const double *pa = xyz + 3 * static_cast<int64_t>(p), *pb = xyz + 3 * static_cast<int64_t>(q);
+              if (pa[0] != pb[0]) return pa[0] < pb[0];
+              if (pa[1] != pb[1]) return pa[1] < pb[1];
+              if (pa[2] != pb[2]) return pa[2] < pb[2];
+              return p < q;
+            });
+          };
+          for (int32_t b = 0; b + 3 < nblk; b += 4) {
+            bool over = false;
+            for (int j = 0; j < 4; ++j) over |= copies[b + j] > budget;
+            if (!over) continue;
+            if (getenv("SAA_PLAN_DEBUG"))
+              fprintf(stderr, "plan:   blocks %d..%d before: %d %d %d %d\n", b, b + 3, copies[b], copies[b + 1], copies[b + 2], copies[b + 3]);
+            const int32_t s0 = block_start[b], s4 = leaf_end(b + 3), m0 = block_start[b + 2] - s0;
+            const int32_t heavy_left = (copies[b] + copies[b + 1] >= copies[b + 2] + copies[b + 3]) ? 1 : 0;
+            std::vector<int32_t> saved(plan.new_to_old.begin() + s0, plan.new_to_old.begin() + s4);
+            const int32_t saved_starts[3] = {block_start[b + 1], block_start[b + 2], block_start[b + 3]};
+            touched.clear();
+            for (int32_t i = s0; i < s4; ++i)
+              for (int64_t j = adj_off[plan.new_to_old[i]]; j < adj_off[plan.new_to_old[i] + 1]; ++j)
+                if (!mark[adj[j]]) {
+                  mark[adj[j]] = 1;
+                  touched.push_back(adj[j]);
+                }
+            for (int32_t e : touched) mark[e] = 0;
+            const int ax = axis_of(s0, s4);
+            bool ok = false;
+            int32_t c4[4] = {0, 0, 0, 0}, st[3] = {0, 0, 0};
+            const int32_t limit = std::max<int32_t>(16, (heavy_left ? m0 : (s4 - s0 - m0)) / 6);
+            for (int32_t moved = 4; moved <= limit && !ok; moved += 4) {
+              const int32_t m = m0 + (heavy_left ? -moved : moved);
+              if (m < 2 || m > s4 - s0 - 2) break;
+              sort_axis(s0, s4, ax);
+              const int32_t lo2[2] = {s0, s0 + m}, hi2[2] = {s0 + m, s4};
+              st[1] = s0 + m;
+              for (int h = 0; h < 2; ++h) {
+                sort_axis(lo2[h], hi2[h], axis_of(lo2[h], hi2[h]));
+                st[2 * h] = lo2[h] + weighted_mid(lo2[h], hi2[h]);
+              }
+              auto count4 = [&]() {
+                const int32_t bounds[5] = {s0, st[0], st[1], st[2], s4};
+                for (int j = 0; j < 4; ++j)
+                  for (int32_t i = bounds[j]; i < bounds[j + 1]; ++i) owner[plan.new_to_old[i]] = b + j;
+                for (int j = 0; j < 4; ++j) c4[j] = 0;
+                for (int32_t e : touched) {
+                  bool in[4] = {false, false, false, false};
+                  for (int a = 0; a < 4; ++a) {
+                    const int32_t o = owner[tets[4 * static_cast<int64_t>(e) + a]] - b;
+                    if (o >= 0 && o < 4) in[o] = true;
+                  }
+                  for (int j = 0; j < 4; ++j) c4[j] += in[j];
+                }
+                if (extra_work)
+                  for (int32_t i = s0; i < s4; ++i) c4[owner[plan.new_to_old[i]] - b] += extra_work[plan.new_to_old[i]];
+              };
+              // (the weights only approximate the copies: the cut inside each pair then follows the copies themselves)
+              for (int it = 0; it < 40; ++it) {
+                count4();
+                bool changed = false;
+                for (int h = 0; h < 2; ++h) {
+                  const int32_t d = c4[2 * h] - c4[2 * h + 1];
+                  if (std::abs(d) <= 12) continue;
+                  const int32_t nk = st[2 * h] + (d > 0 ? -2 : 2);
+                  if (nk <= lo2[h] + 1 || nk >= hi2[h] - 1) continue;
+                  st[2 * h] = nk;
+                  changed = true;
+                }
+                if (!changed) break;
+              }
+              ok = c4[0] <= budget && c4[1] <= budget && c4[2] <= budget && c4[3] <= budget;
+            }
+            if (ok) {
+              const int32_t bounds[5] = {s0, st[0], st[1], st[2], s4};
+              for (int j = 0; j < 4; ++j) {
+                lex_sort(bounds[j], bounds[j + 1]);
+                copies[b + j] = c4[j];
+              }
+              block_start[b + 1] = st[0];
+              block_start[b + 2] = st[1];
+              block_start[b + 3] = st[2];
+              ++repaired4;
+            } else {  // as it was
+              std::copy(saved.begin(), saved.end(), plan.new_to_old.begin() + s0);
+              block_start[b + 1] = saved_starts[0];
+              block_start[b + 2] = saved_starts[1];
+              block_start[b + 3] = saved_starts[2];
+              for (int j = 0; j < 4; ++j)
+                for (int32_t i = (j == 0 ? s0 : block_start[b + j]); i < (j == 3 ? s4 : block_start[b + j + 1]); ++i)
+                  owner[plan.new_to_old[i]] = b + j;
+            }
+            if (getenv("SAA_PLAN_DEBUG"))
+              fprintf(stderr, "plan:   blocks %d..%d: %s one level up (last trial %d %d %d %d)\n", b, b + 3, ok ? "repaired" : "not repaired",
+                      c4[0], c4[1], c4[2], c4[3]);
+          }
+        }
+        if (getenv("SAA_PLAN_DEBUG"))
+          fprintf(stderr, "plan: chunk repair: budget %d copies per block (%d second-phase chunks), %d pairs repaired, %d not, %d groups of "
+                          "four one level up\n", budget, chunks, repaired, failed, repaired4);
+      }
+    }
   } else {
     rcb.split(0, n_nodes, nb);
   }
@@ -900,6 +1176,16 @@ bool build_once(int32_t n_nodes, int32_t n_elems, const double *xyz, const int32
   std::atomic<int32_t> q_hist[12] = {};
   const char *alt_env = getenv("SAA_PLAN_FIXED_AXES");
   const bool alt_axes = !(alt_env && alt_env[0] == '1');
+  // One block per CU and 1024-thread workgroups (api: pick_threads): the resident kernel runs a block's first 1024
+  // interior items before the halo arrives and EVERYTHING else as one second list - further interior items together with
+  // the boundary items, packed together.  As two lists (interior remainder, boundary) each was rounded up to whole 64-item
+  // chunks: a block's ~2530 items then are 41 chunks for 74 of the 256 blocks of the 1M-tet beam instead of 40, one of the
+  // four SIMDs gets 11 chunks instead of 10, and since every block waits for its neighbours those blocks pace all.
+  int64_t max_copies = 0;
+  for (int32_t b = 0; b < n_blocks; ++b) max_copies = std::max<int64_t>(max_copies, off[b + 1] - off[b]);
+  const char *cap_env = getenv("SAA_PLAN_FIRST_ROUND_CAP");
+  const bool cap_on = !(cap_env && cap_env[0] == '0');
+  const int32_t first_round_cap = (cap_on && n_blocks <= 256 && max_copies >= 4096) ? 1024 : INT32_MAX;
   std::atomic<int32_t> next{0};
   auto work = [&](unsigned t) {
     std::vector<uint16_t> items, items_s, part_a, part_b, part_q, loc_b, trial, pi;
@@ -950,6 +1236,12 @@ bool build_once(int32_t n_nodes, int32_t n_elems, const double *xyz, const int32
         interior[i] = in;
         n_in += in;
         paired += it[5];
+      }
+      if (n_in > first_round_cap) {  // interior items beyond the first round join the second list
+        int32_t kept = 0;
+        for (int32_t i = 0; i < ni; ++i)
+          if (interior[i] && ++kept > first_round_cap) interior[i] = 0;
+        n_in = first_round_cap;
       }
       int32_t wi = 0, wb = n_in;
       for (int32_t i = 0; i < ni; ++i) {
@@ -1020,7 +1312,17 @@ bool build_once(int32_t n_nodes, int32_t n_elems, const double *xyz, const int32
       part_a.swap(best.pa);
       part_b.swap(best.pb);
       const PackStats st_in = best.si, st_bd = best.sb;
-      const int32_t m_in = best.mi, m_bd = best.mb;
+      int32_t m_in = best.mi, m_bd = best.mb;
+      if (m_in > first_round_cap) {  // idle slots of the packing pushed the first list past one round: its tail goes last
+        for (int32_t sl = first_round_cap; sl < m_in; ++sl) {
+          const uint16_t *it = &part_a[8 * static_cast<size_t>(sl)];
+          if (it[5] == 2) continue;
+          part_b.insert(part_b.end(), it, it + 8);
+          ++m_bd;
+        }
+        part_a.resize(8 * static_cast<size_t>(first_round_cap));
+        m_in = first_round_cap;
+      }
       stats[t].add(st_in);
       stats[t].add(st_bd);
       out = part_a;
@@ -1125,6 +1427,15 @@ bool build_once(int32_t n_nodes, int32_t n_elems, const double *xyz, const int32
       for (int c = 0; c < 64; ++c)
         if (ch[c]) fprintf(stderr, " %d:%d", c, ch[c]);
       fprintf(stderr, "\n");
+      int ch1[64] = {}, over = 0;  // with ONE rounding: ceil((items - 1024) / 64)
+      for (const auto &b : plan.blocks) {
+        ++ch1[std::min(63, (std::max(b.n_elem - 1024, 0) + 63) / 64)];
+        over += b.n_elem > 2560;
+      }
+      fprintf(stderr, "plan: the same with the interior remainder unpadded:");
+      for (int c = 0; c < 64; ++c)
+        if (ch1[c]) fprintf(stderr, " %d:%d", c, ch1[c]);
+      fprintf(stderr, "; blocks above 2560 items: %d\n", over);
     }
     int hist[8][8] = {};
     for (const auto &b : plan.blocks)

@@ -130,7 +130,9 @@ def test_block_plan_of_a_shuffled_jittered_mesh_finds_the_pairs_and_the_classes(
     assert s["n_blocks"] == j["n_blocks"] == 256
     # the lattice as in round 2: nothing of the new machinery may touch it
     assert s["n_pairs"] > 0.998 * s["n_elem_copies"] / 2 and s["n_by_construction"] > 0.55 * s["n_items"]
-    assert s["lds_conflict_factor"] < 1.33 and s["lds_atomic_conflict_factor"] < 1.17
+    # (atomics 1.135 while the interior remainder was a list of its own; packed together with the boundary items - one
+    # rounding to whole chunks instead of two, every block of this mesh at 40 chunks - 1.175, reads 1.222 -> 1.216)
+    assert s["lds_conflict_factor"] < 1.33 and s["lds_atomic_conflict_factor"] < 1.19
     # the disturbed lattice
     assert j["n_pairs"] > 0.985 * j["n_elem_copies"] / 2, j
     assert j["n_items"] < 1.03 * s["n_items"], (j["n_items"], s["n_items"])
