@@ -20,7 +20,9 @@ struct BlockDesc {
   int32_t n_halo;
   int32_t elem_off;    // offset into conn, in work items
   int32_t n_elem;      // work items of the block (pairs of face-adjacent elements, or single elements)
-  int32_t n_interior;  // items [0,n_interior) touch owned nodes only; the rest need halo records
+  int32_t n_interior;  // items [0,n_interior) touch owned nodes only and may run before the halo records arrive; the rest
+                       // wait for them.  (One block per CU, 1024 threads: at most 1024 - one round; further all-owned
+                       // items are packed into the second list together with those that need halo records.)
   int32_t reserved;    // (keeps the descriptor at 32 bytes)
 };
 
