@@ -759,6 +759,7 @@ bool build_once(int32_t n_nodes, int32_t n_elems, const double *xyz, const int32
   too_big = false;
   if (overflow) *overflow = 0;
   int32_t chunk_capacity = 0;
+  bool second_list_pays = false;  // decided with the chunk repair below
   plan = Plan();
   plan.n_nodes = n_nodes;
   plan.n_elems = n_elems;
@@ -789,10 +790,16 @@ bool build_once(int32_t n_nodes, int32_t n_elems, const double *xyz, const int32
         for (int32_t i = 0; i < n_nodes; ++i)
           for (int a = 0; a < 3; ++a) lo[a] = std::min(lo[a], xyz[3 * static_cast<int64_t>(i) + a]);
         cell.resize(3 * static_cast<size_t>(n_nodes));
+        double dev = 0.0;  // largest distance of a node from its cell's lattice point, in mesh sizes
         for (int32_t i = 0; i < n_nodes; ++i)
-          for (int a = 0; a < 3; ++a)
-            cell[3 * static_cast<size_t>(i) + a] = static_cast<int32_t>(std::floor((xyz[3 * static_cast<int64_t>(i) + a] - lo[a]) / h + 0.5));
-        rcb.cell = cell.data();
+          for (int a = 0; a < 3; ++a) {
+            const double u = (xyz[3 * static_cast<int64_t>(i) + a] - lo[a]) / h, r = std::floor(u + 0.5);
+            cell[3 * static_cast<size_t>(i) + a] = static_cast<int32_t>(r);
+            dev = std::max(dev, std::fabs(u - r));
+          }
+        // an exact lattice keeps the plain order (ties by node id: whatever strips the caller's numbering gives - measured
+        // 0.8 % better than strips by cell on the slabs of the 8-GPU partition, whose local numbering is first-touch)
+        if (dev > 1e-6) rcb.cell = cell.data();
       }
     }
   }
@@ -883,10 +890,15 @@ bool build_once(int32_t n_nodes, int32_t n_elems, const double *xyz, const int32
         mx = std::max(mx, c);
       }
       mean /= nblk;
-      if (mx >= 4096) {  // (what pick_threads answers with 1024 threads)
-        // items ~ copies / 2 + a few single elements and idle slots; the chunk count the mean fits with 0.4 % to spare
-        const double mean_items = 0.5 * mean + 6.0;
-        const int32_t chunks = static_cast<int32_t>(std::ceil((1.004 * mean_items - 1024.0) / 64.0));
+      // items ~ copies / 2 + a few single elements and idle slots; the chunk count the mean fits with 0.4 % to spare
+      const double mean_items = 0.5 * mean + 6.0;
+      const int32_t chunks = static_cast<int32_t>(std::ceil((1.004 * mean_items - 1024.0) / 64.0));
+      // 16 chunks of the first round + `chunks` on four SIMDs: only when that is a multiple of four does one chunk more
+      // (the second rounding of two separate lists, a block a few items over) cost a SIMD a whole further chunk.  41 or 42
+      // chunks put 11 on the busiest SIMD either way - the slabs of the 8-GPU partition: the one-list layout and the repair
+      // then only cost their somewhat worse packing (+0.3 ... 0.9 % measured), so they stay off.
+      second_list_pays = mx >= 4096 && (16 + std::max(chunks, 0)) % 4 == 0;
+      if (second_list_pays) {  // (mx >= 4096: what pick_threads answers with 1024 threads)
         const int32_t budget = 2 * (1024 + 64 * std::max(chunks, 0) - repair_margin);
         chunk_capacity = 1024 + 64 * std::max(chunks, 0);
         // node -> elements
@@ -1237,7 +1249,7 @@ bool build_once(int32_t n_nodes, int32_t n_elems, const double *xyz, const int32
   for (int32_t b = 0; b < n_blocks; ++b) max_copies = std::max<int64_t>(max_copies, off[b + 1] - off[b]);
   const char *cap_env = getenv("SAA_PLAN_FIRST_ROUND_CAP");
   const bool cap_on = !(cap_env && cap_env[0] == '0');
-  const int32_t first_round_cap = (cap_on && n_blocks <= 256 && max_copies >= 4096) ? 1024 : INT32_MAX;
+  const int32_t first_round_cap = (cap_on && second_list_pays && n_blocks <= 256 && max_copies >= 4096) ? 1024 : INT32_MAX;
   std::atomic<int32_t> next{0};
   auto work = [&](unsigned t) {
     std::vector<uint16_t> items, items_s, part_a, part_b, part_q, loc_b, trial, pi;
