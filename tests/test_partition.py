@@ -135,6 +135,10 @@ def test_block_plan_of_a_shuffled_jittered_mesh_finds_the_pairs_and_the_classes(
     assert s["lds_conflict_factor"] < 1.33 and s["lds_atomic_conflict_factor"] < 1.19
     # the disturbed lattice
     assert j["n_pairs"] > 0.985 * j["n_elem_copies"] / 2, j
-    assert j["n_items"] < 1.03 * s["n_items"], (j["n_items"], s["n_items"])
+    # bisection cuts follow layers of the mesh size: the displaced lattice is cut like the lattice itself (ragged block faces
+    # cost 9 % more halo nodes and 1.8 % more element copies before), and what is left of its surplus is single elements
+    assert abs(j["n_halo_total"] - s["n_halo_total"]) < 0.002 * s["n_halo_total"], (j["n_halo_total"], s["n_halo_total"])
+    assert abs(j["n_elem_copies"] - s["n_elem_copies"]) < 0.001 * s["n_elem_copies"]
+    assert j["n_items"] < 1.005 * s["n_items"], (j["n_items"], s["n_items"])
     assert j["n_by_construction"] > 0.5 * j["n_items"], j
     assert j["lds_conflict_factor"] < 1.36 and j["lds_atomic_conflict_factor"] < 1.34, j
