@@ -5,7 +5,8 @@ process order, alternating, so that clocks and box are the same for all of them.
     python tools/ab.py name=path/to/lib.so [name=...] [--cases=resident19,fused19,fused38] [--rounds=3]
 
 Cases: resident<n> (saa_step through the resident kernel, 1000-step launches), resident20x<n> (the same in calls of 20
-steps, wall clock), fused<n> (one launch per step).
+steps, wall clock), fused<n> (one launch per step), predicted<n> (slab 3 of 8 of the n-beam in windows of 50 predicted
+steps, saa_step_predicted, wall clock).
 Each (library, case) runs in a child process (a library is loaded once per process); prints us/step per round and the
 median."""
 import json
@@ -24,8 +25,9 @@ from bench import build_rank_solver, bench_mesh
 case, kind = sys.argv_case
 n = int(''.join(ch for ch in case.split('x')[-1] if ch.isdigit()))
 mesh = bench_mesh(n, kind)
-sol, lay, _, _ = build_rank_solver(mesh, 1, 0, 0)
-resident = case.startswith('resident')
+predicted = case.startswith('predicted')  # BASELINE config 4's per-GPU workload: slab 3 of 8, windows of 50 predicted steps
+sol, lay, _, _ = build_rank_solver(mesh, 8 if predicted else 1, 3 if predicted else 0, 0)
+resident = case.startswith('resident') or predicted
 if not resident:
     sol.set_resident_kernel(False)
 assert sol.resident_kernel_info()['capable'] == resident, sol.resident_kernel_info()
@@ -40,6 +42,21 @@ if case.startswith('resident20x'):  # calls of 20 steps (the driver's --steps 20
         return 1e6 * (time.perf_counter() - t0) / 8000
     run()
     out = [run() for _ in range(3)]
+elif predicted:
+    import torch
+    w = 3 * len(lay.shared_local)
+    table = torch.from_numpy(np.random.default_rng(0).uniform(-1e-6, 1e-6, size=(50, w))).cuda()
+    hist = torch.zeros((50, w), dtype=torch.float64, device='cuda')
+    def run():
+        sol.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(200):
+            sol.step_predicted(50, table, 0, hist, 0)
+        sol.synchronize()
+        return 1e6 * (time.perf_counter() - t0) / 10000
+    run()
+    out = [run() for _ in range(3)]
+    assert torch.equal(hist, table)
 else:
     steps = 4000 if resident else (1000 if n < 30 else 300)
     sol.time_steps(steps)
