@@ -438,13 +438,21 @@ def run_ground_truth(ranks, dt, n_steps, alpha=0.5, snapshots=()):
 
 
 def run_hybrid(ranks, dt, n_steps, shared_local_dofs, predictor, n_past, n_future, filter_size,
-               alpha=0.5):
+               alpha=0.5, resync_every=None, resync_steps=None):
     """Online_predictor.py:251-318 for all ranks.
 
     ``predictor(rank, n, d_sol_shared) -> (n_future*filter_size, input_size)`` plays
     ``encoder_decoder_predictor``.  Returns per-rank saved trajectories (n_dof, n_steps) and the
     shared-dof histories (n_steps, input_size).
+
+    ``resync_every`` (None: the reference, which never synchronises again after the warm-up) is the extension
+    BASELINE.json's configs[4] names ("RCCL every k-th step only"), not reference behaviour: after every
+    ``resync_every`` predicted windows the next ``resync_steps`` steps (default: one window) are synchronised ones,
+    recorded in the history like the warm-up's, so that the following windows are predicted from true values again.
     """
+    if resync_steps is None:
+        resync_steps = n_future * filter_size
+    resync_left, windows = 0, 0
     P = len(ranks)
     i_cri = n_past * filter_size - 1
     d0s = [np.zeros((len(rp.local_dof), 1)) for rp in ranks]
@@ -455,7 +463,8 @@ def run_hybrid(ranks, dt, n_steps, shared_local_dofs, predictor, n_past, n_futur
     i = 0
     counter2 = 0
     while i < n_steps:
-        if i <= i_cri:
+        if i <= i_cri or resync_left > 0:
+            resync_left = max(resync_left - 1, 0)
             if P == 1:
                 rp = ranks[0]
                 d1s = [explicit_step(rp.K, rp.F, rp.dirichlet, tn, dt, d0s[0], dns[0], rp.l_M, alpha)]
@@ -479,7 +488,7 @@ def run_hybrid(ranks, dt, n_steps, shared_local_dofs, predictor, n_past, n_futur
                 d1s = []
                 for r, rp in enumerate(ranks):
                     d1 = explicit_step(rp.K, rp.F, rp.dirichlet, tn, dt, d0s[r], dns[r], rp.l_M, alpha)
-                    row = k - i_cri - 1 - n_future * filter_size * counter2
+                    row = k - start  # (= k - i_cri - 1 - n_future * filter_size * counter2 in the reference's counting)
                     d1[shared_local_dofs[r]] = tables[r][row, :].reshape((-1, 1))
                     hist[r][i, :] = d1[shared_local_dofs[r], 0]
                     save[r][:, i] = d1[:, 0]
@@ -488,4 +497,7 @@ def run_hybrid(ranks, dt, n_steps, shared_local_dofs, predictor, n_past, n_futur
                 i += 1
                 tn = tn + dt
             counter2 += 1
+            windows += 1
+            if resync_every and windows % resync_every == 0:
+                resync_left = resync_steps
     return save, hist

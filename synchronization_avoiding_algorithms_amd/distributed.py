@@ -230,14 +230,27 @@ class PartitionedSolver:
         self.solver.close()
 
 
-def run_hybrid(part: PartitionedSolver, n_steps, predictor, n_past, n_future, filter_size, save=None):
+def run_hybrid(part: PartitionedSolver, n_steps, predictor, n_past, n_future, filter_size, save=None, resync_every=None,
+               resync_steps=None):
     """``Online_predictor.py:251-318`` on one rank.
 
     ``predictor(n, hist) -> table``: ``hist`` is the ``(n_steps, input_size)`` float64 history tensor on the
     solver's device (``d_sol_shared``), the result a ``(n_future*filter_size, input_size)`` float64 tensor
     (``encoder_decoder_predictor``).  ``save(i, part)`` is called after every step that the reference would
     store (``save_every`` logic lives in the callback).  Returns the history tensor.
+
+    ``resync_every=k`` is an extension, not reference behaviour (the reference never synchronises again after the warm-up;
+    BASELINE.json's configs[4] asks for "RCCL every k-th step only"): after every ``k`` predicted windows the next
+    ``resync_steps`` steps (default: one window, ``n_future*filter_size``) exchange the shared-node forces like the warm-up
+    does and record their true values in the history, from which the following windows are predicted.  Every rank must
+    pass the same values: synchronised steps are collective.
     """
+    if resync_every is not None and int(resync_every) < 1:
+        raise ValueError("resync_every must be a positive number of windows (or None)")
+    if resync_steps is None:
+        resync_steps = n_future * filter_size
+    if int(resync_steps) < 1:
+        raise ValueError("resync_steps must be positive")
     import torch
 
     hist = torch.zeros((n_steps, max(part.input_size, 1)), dtype=torch.float64, device=part.tensor_device)
@@ -245,12 +258,16 @@ def run_hybrid(part: PartitionedSolver, n_steps, predictor, n_past, n_future, fi
     hist = hist.contiguous()
     i_cri = n_past * filter_size - 1
     window = n_future * filter_size
-    i = 0
+    i, resync_left, windows = 0, 0, 0
     while i < n_steps:
-        if i <= i_cri:
-            n = min(i_cri + 1, n_steps) - i if save is None else 1
+        if i <= i_cri or resync_left > 0:
+            warm_up = i <= i_cri  # (no window has run yet: resync_left is 0)
+            todo = i_cri + 1 - i if warm_up else resync_left
+            n = min(todo, n_steps - i) if save is None else 1
             part.step_synced(n, hist if part.input_size else None, i)
             i += n
+            if not warm_up:
+                resync_left -= n
             if save is not None:
                 save(i - 1, part)
         else:
@@ -264,4 +281,7 @@ def run_hybrid(part: PartitionedSolver, n_steps, predictor, n_past, n_future, fi
                     part.step_predicted(1, table, k, hist if part.input_size else None, i)
                     i += 1
                     save(i - 1, part)
+            windows += 1
+            if resync_every and windows % int(resync_every) == 0:
+                resync_left = int(resync_steps)
     return hist

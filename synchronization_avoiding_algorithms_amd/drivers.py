@@ -165,8 +165,11 @@ def shared_extraction(out_dir=".", rank=0):
 
 def online_predictor(mesh, n_steps=100000, save_every=1, out_dir=".", rank=0, world=1, partition="slab",
                      device=0, n_past=20, n_future=20, filter_size=150, hidden_size=50, nB=10,
-                     learning_rate=5e-4, cut_off=0.5, model=None, scale=None, epart=None, **part_kw):
-    """``Online_predictor.py:116-324``: warm-up with synchronisation, then LSTM-predicted halos."""
+                     learning_rate=5e-4, cut_off=0.5, model=None, scale=None, epart=None, resync_every=None,
+                     resync_steps=None, **part_kw):
+    """``Online_predictor.py:116-324``: warm-up with synchronisation, then LSTM-predicted halos.  ``resync_every`` /
+    ``resync_steps``: synchronised steps again after every so many predicted windows (an extension, see
+    :func:`distributed.run_hybrid`; None = the reference, which never synchronises again)."""
     import torch
 
     epart = make_partition(mesh, world, partition) if epart is None else epart
@@ -184,7 +187,8 @@ def online_predictor(mesh, n_steps=100000, save_every=1, out_dir=".", rank=0, wo
     store, save = (None, None) if traj is not None else _saver(part, n_steps, save_every)
     with torch.no_grad():
         hist = run_hybrid(part, n_steps, pr.DevicePredictor(model, n_past, n_future, filter_size, *scale),
-                          n_past, n_future, filter_size, save=save)
+                          n_past, n_future, filter_size, save=save, resync_every=resync_every,
+                          resync_steps=resync_steps)
     if traj is not None:
         part.solver.synchronize()
         store = traj.cpu().numpy()
@@ -219,6 +223,10 @@ def main(argv=None):
     ap.add_argument("--n-future", type=int, default=20)
     ap.add_argument("--filter-size", type=int, default=150)
     ap.add_argument("--hidden-size", type=int, default=50)
+    ap.add_argument("--resync-every", type=int, default=None,
+                    help="online_predictor: synchronised steps again after every so many predicted windows (extension; "
+                         "default: never, like the reference)")
+    ap.add_argument("--resync-steps", type=int, default=None, help="how many (default: one window, n_future*filter_size)")
     args = ap.parse_args(argv)
     rank, world, local = _dist_env()
     if args.command == "data_prepare":
@@ -240,7 +248,8 @@ def main(argv=None):
     else:
         path, _, _ = online_predictor(_load_mesh(args), args.steps, args.save_every, args.out, rank, world,
                                       args.partition, device=local, n_past=args.n_past, n_future=args.n_future,
-                                      filter_size=args.filter_size, hidden_size=args.hidden_size)
+                                      filter_size=args.filter_size, hidden_size=args.hidden_size,
+                                      resync_every=args.resync_every, resync_steps=args.resync_steps)
     print(f"[rank {rank}] wrote {path}")
 
 

@@ -114,6 +114,55 @@ def test_reference_workflow_on_gpu(tmp_path):
             assert any(os.path.exists(base + ext) for ext in (".csv", ".hdf5", ".npz")), base
 
 
+def _resync_worker(rank, world, port, out_dir):
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from synchronization_avoiding_algorithms_amd import drivers
+    from synchronization_avoiding_algorithms_amd import predictor as pr
+    from synchronization_avoiding_algorithms_amd.mesh import Mesh
+
+    g = np.load(os.path.join(GOLDEN, "beam_coarse_mesh.npz"))
+    h = np.load(os.path.join(GOLDEN, "hybrid_tworank.npz"))
+    mesh = Mesh(g["points"], {"tetra": g["tetra"], "triangle": g["triangle"]})
+    T, n_p, n_f, n_s, hid = (int(h[k]) for k in ("test_num", "n_past", "n_future", "filter_size", "hidden_size"))
+    model = pr.LSTM_encoder_decoder(int(h[f"r{rank}_loc_dof_shared"].size), hid)
+    model.load_state_dict({k[len(f"r{rank}_w::"):]: torch.from_numpy(h[k]) for k in h.files if k.startswith(f"r{rank}_w::")})
+    # (on the GPU the trajectory is recorded by the step kernels themselves: whole windows and whole re-synchronisations
+    # per call, drivers._device_recorder)
+    _, modeled, hist = drivers.online_predictor(mesh, T, 1, out_dir, rank, world, epart=h["epart"], n_past=n_p,
+                                                n_future=n_f, filter_size=n_s, hidden_size=hid, model=model,
+                                                scale=tuple(float(v) for v in h[f"r{rank}_scale"]),
+                                                resync_every=2, resync_steps=7)
+    out = dict(modeled=modeled, hist=hist.cpu().numpy())
+    dist.barrier()
+    np.savez(os.path.join(out_dir, f"rs{rank}.npz"), **out)
+    dist.destroy_process_group()
+
+
+def test_hybrid_loop_with_resynchronisation_on_gpu(tmp_path):
+    """BASELINE.json configs[4]'s "RCCL every k-th step only" (an extension; the reference never synchronises again):
+    Online_predictor with 7 synchronised steps after every 2 predicted windows, HIP solver + native predictor, two ranks,
+    against the oracle's loop with the same schedule (tests/test_distributed_gloo.py has the CPU twin)."""
+    from conftest import oracle_hybrid_tworank
+
+    port = free_port()
+    mp.spawn(_resync_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    save, hist = oracle_hybrid_tworank(resync_every=2, resync_steps=7)
+    h = load_golden("hybrid_tworank.npz")
+    for r in range(2):
+        got = np.load(tmp_path / f"rs{r}.npz")
+        assert rel_l2(got["modeled"], save[r]) < 1e-4 and rel_l2(got["hist"], hist[r]) < 1e-4
+        assert rel_l2(got["modeled"][:, :20], save[r][:, :20]) < 1e-12   # warm-up: fp64
+        # the steps of a re-synchronisation start from predicted values and are fp64 from there: the history rows they
+        # record are the shared dofs of the state they produced
+        loc = h[f"r{r}_loc_dof_shared"]
+        for i in (60, 66, 107, 113):
+            assert np.array_equal(got["hist"][i], got["modeled"][loc, i])
+        assert rel_l2(got["modeled"][:, :60], h[f"r{r}_modeled"][:, :60]) < 1e-4   # the reference's own run until step 60
+
+
 def drivers_path(key, r):
     from synchronization_avoiding_algorithms_amd import drivers
 
