@@ -33,6 +33,9 @@ def main():
     ap.add_argument("--sequential-training", action="store_true",
                     help="ranks sharing one GPU train one after the other (each with the graphed optimiser step) instead "
                          "of at the same time with eager launches: what a full-schedule run on a one-GPU box wants")
+    ap.add_argument("--resync-every", default="",
+                    help="comma-separated k: after the reference's loop, run the sync-avoiding part again with synchronised "
+                         "steps (one window) after every k predicted windows - an extension, drivers.online_predictor")
     args = ap.parse_args()
     if args.epochs <= 0:  # the reference's schedule: until the decayed rate reaches lr_min (Model_training.py:65)
         args.epochs = None
@@ -79,14 +82,28 @@ def main():
                                              filter_size=args.filter_size, hidden_size=args.hidden_size)
     t3 = time.time()
     i_cri = 20 * args.filter_size
-    err_all = np.linalg.norm(modeled - truth) / np.linalg.norm(truth)
-    err_pred = np.linalg.norm(modeled[:, i_cri:] - truth[:, i_cri:]) / np.linalg.norm(truth[:, i_cri:])
-    # the field at the end of every predicted window (n_future * filter_size steps each, Online_predictor.py:284)
     win = 20 * args.filter_size
-    ends = list(range(i_cri + win - 1, modeled.shape[1], win))
-    per_window = [float(np.linalg.norm(modeled[:, e] - truth[:, e]) / np.linalg.norm(truth[:, e])) for e in ends]
+
+    def errors(modeled):
+        err_all = np.linalg.norm(modeled - truth) / np.linalg.norm(truth)
+        err_pred = np.linalg.norm(modeled[:, i_cri:] - truth[:, i_cri:]) / np.linalg.norm(truth[:, i_cri:])
+        # the field at the end of every window (n_future * filter_size steps each, Online_predictor.py:284)
+        ends = list(range(i_cri + win - 1, modeled.shape[1], win))
+        return err_all, err_pred, [float(np.linalg.norm(modeled[:, e] - truth[:, e]) / np.linalg.norm(truth[:, e])) for e in ends]
+
+    err_all, err_pred, per_window = errors(modeled)
     print(f"[rank {rank}] rel-L2 of the rank's displacement field at the end of predicted window 1.."
           f"{len(per_window)}: " + " ".join(f"{v:.2e}" for v in per_window), flush=True)
+    for k in [int(v) for v in args.resync_every.split(",") if v]:
+        barrier()
+        tk = time.time()
+        _, again, _ = drivers.online_predictor(mesh, args.steps, 1, args.out, rank, world, device=local,
+                                               filter_size=args.filter_size, hidden_size=args.hidden_size, resync_every=k)
+        _, e_pred, e_win = errors(again)
+        n_sync = sum(1 for w in range(len(e_win)) if w % (k + 1) == k)
+        print(f"[rank {rank}] one synchronised window after every {k} predicted ones ({n_sync} of {len(e_win)} windows "
+              f"synchronised, {time.time() - tk:.1f} s): {e_pred:.3e} over the phase after the warm-up; at the window ends: "
+              + " ".join(f"{v:.2e}" for v in e_win), flush=True)
     print(f"[rank {rank}] steps {args.steps}: data_prepare {t1 - t0:.1f} s, extraction+training ({len(tl)} epochs, "
           f"final train/val MSE {tl[-1]:.3e}/{vl[-1]:.3e}) {t2 - t1:.1f} s, online_predictor {t3 - t2:.1f} s; "
           f"rel-L2(sync-avoiding vs synchronised) = {err_all:.3e} overall, {err_pred:.3e} over the predicted phase",

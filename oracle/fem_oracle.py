@@ -449,6 +449,7 @@ def run_hybrid(ranks, dt, n_steps, shared_local_dofs, predictor, n_past, n_futur
     BASELINE.json's configs[4] names ("RCCL every k-th step only"), not reference behaviour: after every
     ``resync_every`` predicted windows the next ``resync_steps`` steps (default: one window) are synchronised ones,
     recorded in the history like the warm-up's, so that the following windows are predicted from true values again.
+    They start from the mean of the holders' copies of every shared node (d^n and d^(n-1)).
     """
     if resync_steps is None:
         resync_steps = n_future * filter_size
@@ -500,4 +501,18 @@ def run_hybrid(ranks, dt, n_steps, shared_local_dofs, predictor, n_past, n_futur
             windows += 1
             if resync_every and windows % resync_every == 0:
                 resync_left = resync_steps
+                # the holders' copies of a shared node have gone their own ways (every rank wrote ITS model's values): they
+                # continue from their mean, d^n and d^(n-1) alike (distributed.PartitionedSolver.reconcile_shared)
+                for d in (d0s, dns):
+                    tot, cnt = np.zeros(3 * ranks[0].n_global), np.zeros(3 * ranks[0].n_global)
+                    gdofs = []
+                    for r, rp in enumerate(ranks):
+                        ld = np.asarray(shared_local_dofs[r])
+                        gd = 3 * np.asarray(rp.nodes)[ld // 3] + ld % 3
+                        gdofs.append((ld, gd))
+                        np.add.at(tot, gd, d[r][ld, 0])
+                        np.add.at(cnt, gd, 1.0)
+                    for r, (ld, gd) in enumerate(gdofs):
+                        d[r] = d[r].copy()
+                        d[r][ld, 0] = tot[gd] / cnt[gd]
     return save, hist

@@ -222,6 +222,27 @@ class PartitionedSolver:
         self.solver.step_predicted(nsteps, table, table_row0, hist, hist_row0)
         self.steps_done += nsteps
 
+    def reconcile_shared(self):
+        """COLLECTIVE.  Every holder's copy of a shared node's d^n and d^(n-1) is replaced by the mean over its holders.
+        In predicted steps every rank writes ITS model's values into its copy (``Online_predictor.py:298``), so the
+        copies differ; synchronised steps sum the forces but update each copy from itself, so the copies would stay apart
+        (and keep a difference in velocity).  Not in the reference, which never returns to synchronised steps."""
+        import torch
+        import torch.distributed as dist
+
+        if self.world == 1:
+            return
+        d0, dn, tn = self.solver.get_state()
+        loc = np.asarray(self.layout.loc_dof_shared, dtype=np.int64)
+        gd = (3 * np.asarray(self.layout.shared_slots, dtype=np.int64)[:, None] + np.arange(3)[None, :]).ravel()
+        buf = np.zeros((3, 3 * len(self.global_shared)))
+        buf[0, gd], buf[1, gd], buf[2, gd] = d0[loc, 0], dn[loc, 0], 1.0
+        t = torch.from_numpy(buf).to(self.tensor_device)
+        dist.all_reduce(t, group=self.group)  # (every rank receives the same sums: the copies end up bit-identical)
+        buf = t.cpu().numpy()
+        d0[loc, 0], dn[loc, 0] = buf[0, gd] / buf[2, gd], buf[1, gd] / buf[2, gd]
+        self.solver.set_state(d0, dn, tn)
+
     # -- convenience ---------------------------------------------------------------------------------
     def get_state(self):
         return self.solver.get_state()
@@ -242,8 +263,11 @@ def run_hybrid(part: PartitionedSolver, n_steps, predictor, n_past, n_future, fi
     ``resync_every=k`` is an extension, not reference behaviour (the reference never synchronises again after the warm-up;
     BASELINE.json's configs[4] asks for "RCCL every k-th step only"): after every ``k`` predicted windows the next
     ``resync_steps`` steps (default: one window, ``n_future*filter_size``) exchange the shared-node forces like the warm-up
-    does and record their true values in the history, from which the following windows are predicted.  Every rank must
-    pass the same values: synchronised steps are collective.
+    does and record their true values in the history, from which the following windows are predicted; they start from the
+    mean of the holders' copies of every shared node (:meth:`PartitionedSolver.reconcile_shared`).  Every rank must pass
+    the same values: synchronised steps are collective.  Measured on the reference's example it does not pay - the field
+    gets worse inside every synchronised window and with ``k = 1`` the loop diverges (DESIGN.md section 5,
+    ``profiles/r03_resync_every_k.txt``): off by default.
     """
     if resync_every is not None and int(resync_every) < 1:
         raise ValueError("resync_every must be a positive number of windows (or None)")
@@ -282,6 +306,7 @@ def run_hybrid(part: PartitionedSolver, n_steps, predictor, n_past, n_future, fi
                     i += 1
                     save(i - 1, part)
             windows += 1
-            if resync_every and windows % int(resync_every) == 0:
+            if resync_every and windows % int(resync_every) == 0 and i < n_steps:
                 resync_left = int(resync_steps)
+                part.reconcile_shared()
     return hist

@@ -149,6 +149,15 @@ def test_two_rank_hybrid_loop_with_resynchronisation_matches_the_oracle(tmp_path
         # per-step calls and whole-window calls are the same run
         assert np.array_equal(got["hist_windows"], got["hist"])
         assert np.array_equal(got["last_windows"], got["saved"][:, -1])
+    # a re-synchronisation starts from the mean of the two copies of every shared node (reconcile_shared): through its
+    # steps the ranks hold the same values there, while in the predicted steps before it each had its own model's
+    t = load_golden("tworank_trajectory.npz")
+    cols = [np.argsort(np.repeat(3 * t[f"r{r}_shared_nodes"], 3) + np.tile(np.arange(3), len(t[f"r{r}_shared_nodes"])))
+            for r in range(2)]
+    a, b = (np.load(tmp_path / f"hyb{r}.npz")["hist"][:, cols[r]] for r in range(2))
+    for rows in (slice(60, 67), slice(107, 114)):
+        assert rel_l2(a[rows], b[rows]) < 1e-13
+    assert rel_l2(a[40:60], b[40:60]) > 1e-6
 
 
 def test_run_hybrid_rejects_a_schedule_of_nothing():
