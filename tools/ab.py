@@ -6,7 +6,8 @@ process order, alternating, so that clocks and box are the same for all of them.
 
 Cases: resident<n> (saa_step through the resident kernel, 1000-step launches), resident20x<n> (the same in calls of 20
 steps, wall clock), fused<n> (one launch per step), predicted<n> (slab 3 of 8 of the n-beam in windows of 50 predicted
-steps, saa_step_predicted, wall clock).
+steps, saa_step_predicted, wall clock; predictednohist<n>: without the history record; predictedplain<n>: plain steps
+in the same windows).
 Each (library, case) runs in a child process (a library is loaded once per process); prints us/step per round and the
 median."""
 import json
@@ -51,12 +52,15 @@ elif predicted:
         sol.synchronize()
         t0 = time.perf_counter()
         for _ in range(200):
-            sol.step_predicted(50, table, 0, hist, 0)
+            if 'plain' in case:      # predictedplain<n>: the same slab and window length, exchange-free plain steps
+                sol.step(50)
+            else:                    # predictednohist<n>: the overwrite without the history record
+                sol.step_predicted(50, table, 0, None if 'nohist' in case else hist, 0)
         sol.synchronize()
         return 1e6 * (time.perf_counter() - t0) / 10000
     run()
     out = [run() for _ in range(3)]
-    assert torch.equal(hist, table)
+    assert 'plain' in case or 'nohist' in case or torch.equal(hist, table)
 else:
     steps = 4000 if resident else (1000 if n < 30 else 300)
     sol.time_steps(steps)
