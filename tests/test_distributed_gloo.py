@@ -230,6 +230,60 @@ def test_three_ranks_with_triple_owned_nodes_equal_serial(tmp_path):
     _check_three_ranks(tmp_path, use_gpu=False)
 
 
+def _reconcile_worker(rank, world, port, out_dir):
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from cpu_double import CpuSolverDouble, host_setup_fields
+    from synchronization_avoiding_algorithms_amd.distributed import PartitionedSolver
+    from synchronization_avoiding_algorithms_amd.mesh import structured_beam
+
+    mesh = structured_beam(3, length=4.0)
+    part = PartitionedSolver(mesh.points, mesh.tets, mesh.triangles, _t_partition(mesh), rank, world,
+                             tensor_device=torch.device("cpu"), solver_factory=lambda **k: CpuSolverDouble(**k),
+                             setup_fields=host_setup_fields)
+    rng = np.random.default_rng(10 + rank)  # every rank its own values, on the shared nodes too
+    n = 3 * len(part.layout.nodes)
+    d0, dn = rng.normal(size=n), rng.normal(size=n)
+    part.solver.set_state(d0, dn, 0.375)
+    part.reconcile_shared()
+    a0, an, tn = part.get_state()
+    np.savez(os.path.join(out_dir, f"rc{rank}.npz"), nodes=part.layout.nodes, before0=d0, beforen=dn, after0=a0[:, 0],
+             aftern=an[:, 0], tn=tn)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_reconcile_shared_gives_every_holder_the_mean_of_the_copies(tmp_path):
+    """PartitionedSolver.reconcile_shared (what a re-synchronisation starts from): nodes held by two and by three ranks end
+    up with the mean of their holders' d^n and d^(n-1), bit-identical on all of them; everything else and the time stay."""
+    from synchronization_avoiding_algorithms_amd.mesh import structured_beam
+
+    port = free_port()
+    mp.spawn(_reconcile_worker, args=(3, port, str(tmp_path)), nprocs=3, join=True)
+    got = [np.load(tmp_path / f"rc{r}.npz") for r in range(3)]
+    n_nodes = len(structured_beam(3, length=4.0).points)
+    for key in ("0", "n"):
+        tot, cnt = np.zeros((n_nodes, 3)), np.zeros(n_nodes)
+        for g in got:
+            tot[g["nodes"]] += g["before" + key].reshape(-1, 3)
+            cnt[g["nodes"]] += 1
+        assert cnt.max() == 3 and (cnt == 2).any()
+        for g in got:
+            held = cnt[g["nodes"]]
+            after, before = g["after" + key].reshape(-1, 3), g["before" + key].reshape(-1, 3)
+            assert np.array_equal(after[held == 1], before[held == 1])
+            want = (tot[g["nodes"]] / cnt[g["nodes"]][:, None])[held > 1]
+            assert np.allclose(after[held > 1], want, rtol=1e-15, atol=0)
+        ref = {int(n): v for n, v in zip(got[0]["nodes"], got[0]["after" + key].reshape(-1, 3))}
+        for g in got[1:]:
+            for n, v in zip(g["nodes"], g["after" + key].reshape(-1, 3)):
+                if int(n) in ref:
+                    assert np.array_equal(v, ref[int(n)])  # the same bits on every holder
+    assert all(float(g["tn"]) == 0.375 for g in got)
+
+
 def test_multi_process_cpu_baseline_equals_the_oracle_step():
     """bench.py's P-core CPU baseline (oracle/cpu_baseline_mp.py: one process per slab, shared-node forces summed in
     rank order through shared memory) against the oracle's all-ranks-in-one-process restatement of syn_cpus."""
