@@ -18,9 +18,18 @@ with a non-zero status (`legs`, `leg_seconds`).
 Extra objects on the N = 1 line:
   roofline      contract figure: algorithmic bytes/step (16*Ne + 216*Nn) / HIP-event time on the
                 kernel's own stream, against the 8 TB/s HBM peak of MI355X_MICROARCH.md - an EQUIVALENT bandwidth (what a
-                kernel re-reading the partition every step would have to sustain); next to it what the kernel really
-                moves (`traffic`, `hbm_measured`) and what really bounds it (`onchip`: VALU / LDS / barrier shares and
-                fp64 rate from the committed PMC passes and stamps of the same kernel and mesh).
+                kernel re-reading the partition every step would have to sustain), over a region of >= 1 s (`sustained`)
+                next to the short region earlier rounds quoted; next to it what the kernel really moves (`traffic`,
+                `hbm_measured`) and what really bounds it (`bound`, `onchip`: VALU / LDS / barrier shares and fp64 rate
+                from the committed PMC passes of the same kernel - printed only while the plan of this run is the
+                profiled one).
+  cache_exceeding   BASELINE.json's 8.2M-tet beam on ONE GPU (exceeds the Infinity Cache; one fused launch per step).
+  per_gpu_of_8      the per-GPU workload of configs[3] / configs[4]: rank 3 of the 8 x-slabs of that beam, stepped plain,
+                through the peer exchange with loop-back neighbours, through saa_step_synced with a one-rank RCCL
+                communicator (eager launches / replayed graphs) and through sync-avoiding windows (native predictor at
+                9126 inputs + 3000 predicted steps); `projected_8gpu` = what those step times would give on 8 GPUs if
+                the exchange between GPUs cost what it costs inside one.
+  unstructured  the same 1M-tet box meshed by a Delaunay triangulation of random points (no lattice anywhere).
   cpu_baseline  the CPU oracle ("port": SciPy CSR K.dot + the NumPy update, the reference's own per-step operations)
                 timed on the SAME mesh on one host core and on min(8, cores) cores (one process per x-slab); the GPU
                 steps the same mesh for the parity figure (parity.rel_l2).
@@ -46,7 +55,19 @@ HBM_PEAK = 8.0e12  # B/s, MI355X_MICROARCH.md "HBM3E peak BW"
 FP64_VECTOR_PEAK = 78.6e12
 # mesh refinement per GPU count: 150*n^3 tets ~ N * 1.03M
 N_FOR_GPUS = {1: 19, 2: 24, 3: 27, 4: 30, 5: 32, 6: 34, 7: 36, 8: 38}
-ONCHIP_SUMMARY = os.path.join(REPO, "profiles", "r03_onchip_summary.json")
+PROFILE_ROUNDS = ("r04", "r03")  # committed PMC summaries, newest first: profiles/<round>_pmc_summary.json / _onchip_summary.json
+PLAN_IDENTITY = ("n_blocks", "max_owned", "max_local", "n_elem_copies", "n_halo_total", "lds_bytes", "threads", "n_items",
+                 "n_pairs", "n_by_construction")  # what makes two plans the same work for the same kernel
+
+
+def test_hook(point):
+    """Tests only: ``SAA_BENCH_HOOKS=<module>`` (tests/bench_hooks.py) lets a test misbehave at a named point of the run
+    (a preflight child that hangs, a collective that never returns); nothing of that lives in this file."""
+    name = os.environ.get("SAA_BENCH_HOOKS")
+    if name:
+        import importlib
+
+        importlib.import_module(name).hook(point)
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -168,10 +189,16 @@ class Legs:
 # ---------------------------------------------------------------------------------------------------------------
 def bench_mesh(n, kind):
     """The bench's mesh: the structured ``25n x n x n`` Kuhn-tet beam, or (``--mesh jittered``) the same beam with every
-    interior node moved by up to 20 % of the cube edge and nodes and elements renumbered at random - no lattice
-    structure for the LDS packing to find, like the reference's own Gmsh mesh (Mesh_info/beam_coarse.vtk)."""
+    interior node moved by up to 20 % of the cube edge and nodes and elements renumbered at random, or
+    (``--mesh delaunay``) the same box with the same number of nodes meshed by a Delaunay triangulation of random points -
+    no lattice anywhere, the class of mesh the reference's own Gmsh input is (Mesh_info/beam_US.geo:2-16,
+    Mesh_info/beam_coarse.vtk)."""
     from synchronization_avoiding_algorithms_amd.mesh import Mesh, structured_beam
 
+    if kind == "delaunay":
+        from synchronization_avoiding_algorithms_amd.mesh import delaunay_beam
+
+        return delaunay_beam(n)
     mesh = structured_beam(n)
     if kind == "structured":
         return mesh
@@ -285,11 +312,7 @@ def preflight_main(world, rank, local_rank):
     """Child process of one rank (bench.py --preflight): a tiny partitioned problem stepped through the peer exchange
     on the real devices.  Exit code 0 = the direct xGMI path works here; anything else (including a crash of this
     process) makes the parent fall back to the RCCL all-reduce."""
-    hook = os.environ.get("SAA_BENCH_TEST_PREFLIGHT")  # tests only: a preflight that fails / never returns
-    if hook == "fail":
-        return 3
-    if hook == "hang":
-        time.sleep(3600)
+    test_hook("preflight")
     import torch
     import torch.distributed as dist
 
@@ -302,7 +325,7 @@ def preflight_main(world, rank, local_rank):
 
     mesh = structured_beam(4)
     part = PartitionedSolver(mesh.points, mesh.tets, mesh.triangles, slab_partition(mesh, world), rank, world, E=E, nu=NU,
-                             rho=RHO, fz=FZ, alpha=ALPHA, gamma=GAMMA, device=local_rank, exchange="peer")
+                             rho=RHO, fz=FZ, alpha=ALPHA, gamma=GAMMA, device=local_rank, exchange="peer", wait_timeout_s=20)
     ok = part.exchange == "peer"
     if ok:
         part.step_synced(5)      # one launch per step
@@ -325,7 +348,6 @@ def run_preflight(args, world, limit_s):
     env = dict(os.environ)
     env["MASTER_PORT"] = str(int(env.get("MASTER_PORT", "29500")) + 17)
     env.pop("TORCHELASTIC_USE_AGENT_STORE", None)  # the children's rank 0 hosts their own rendezvous store
-    env["SAA_PEER_TIMEOUT_S"] = env.get("SAA_PEER_TIMEOUT_S", "20")
     cmd = [sys.executable, os.path.abspath(__file__), "--preflight", "--gpus", str(world)]
     if args.same_device:
         cmd.append("--same-device")
@@ -416,7 +438,7 @@ def sync_avoiding_leg(part, args, rank, world, ne_total, fence, train_seconds):
     errs, elapsed, i = [], 0.0, start
     with torch.no_grad():
         part.step_synced(start, hist, 0)
-        for _ in range(3):  # untimed: the PyTorch-ROCm route (SAA_PREDICT_NATIVE=0) captures its HIP graph on the third call
+        for _ in range(3):  # untimed (the PyTorch-ROCm route would capture its HIP graph on the third call)
             predictor(start, hist)
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
         ev[0].record()
@@ -495,16 +517,12 @@ def predictor_leg(device_index):
     nat = pr.NativePredictor(model, n_p, n_f, n_s, device_index)
     table = nat.predict(n, hist, smax, smin).clone()
     t_nat = ms_per_call(lambda: nat.predict(n, hist, smax, smin, table), 40)
-    os.environ["SAA_PREDICT_NATIVE"] = "0"
-    try:
-        with torch.no_grad():
-            graph = pr.DevicePredictor(model, n_p, n_f, n_s, smax, smin)
-            for _ in range(4):
-                want = graph(n, hist)
-            t_pt = ms_per_call(lambda: graph(n, hist), 10)
-            diff = float((table - want).abs().max() / want.abs().max())
-    finally:
-        os.environ.pop("SAA_PREDICT_NATIVE", None)
+    with torch.no_grad():
+        graph = pr.DevicePredictor(model, n_p, n_f, n_s, smax, smin, backend="torch")
+        for _ in range(4):
+            want = graph(n, hist)
+        t_pt = ms_per_call(lambda: graph(n, hist), 10)
+        diff = float((table - want).abs().max() / want.abs().max())
     nat.close()
     D, G, M = 2 * H, 8 * H, n_p * n_s
     flop = 2.0 * (M * I * G + n_s * I * G + n_f * n_s * D * I) + 2.0 * n_s * (n_p * (2 * H * G + D * G) + n_f * D * G)
@@ -521,6 +539,250 @@ def predictor_leg(device_index):
                                  "(profiles/r03_predictor_kernel_trace_saa.csv)"},
             "share_of_a_3000_step_window": f"{t_nat:.2f} ms against ~26 ms of exchange-free stepping per rank "
                                            f"(PyTorch-ROCm: {t_pt:.1f} ms)"}
+
+
+def kernel_sources_digest():
+    """Short digest of the step kernels' sources: a committed counter summary records the one it was measured with."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for name in ("saa_kernels.hip", "saa_device.h", "saa_plan.h"):
+        with open(os.path.join(REPO, "synchronization_avoiding_algorithms_amd", "csrc", name), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def committed_counters(key, stats):
+    """HBM traffic per launch and the on-chip shares of the kernel `key` ("resident19", "fused38", ...) from the newest
+    committed PMC summary (tools/pmc_collect.sh: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes,
+    nothing else enabled; KiB units; FETCH_SIZE doubled: gfx950 counts 64 B per 128-B request, MI355X_MICROARCH.md "HBM").
+    They are figures of ANOTHER run of the same command, so they are only handed out while the plan of this run
+    (`stats`) is the plan that was profiled; otherwise the reason is returned instead.
+    Returns (traffic_bytes | None, onchip record | None, source | None, note | None)."""
+    for rnd in PROFILE_ROUNDS:
+        try:
+            with open(os.path.join(REPO, "profiles", f"{rnd}_pmc_summary.json")) as fh:
+                pmc = json.load(fh)
+            fetch = pmc[f"{rnd}_{key}:FETCH_SIZE"]["mean_per_dispatch"]
+            write = pmc[f"{rnd}_{key}:WRITE_SIZE"]["mean_per_dispatch"]
+        except (OSError, KeyError, ValueError):
+            continue
+        recorded = pmc.get(f"{rnd}_{key}:plan")
+        if recorded is None:
+            return None, None, None, (f"profiles/{rnd}_pmc_summary.json holds counters for {key} but not the plan they were "
+                                      "measured on: not printed")
+        diff = {k: (recorded.get(k), stats.get(k)) for k in PLAN_IDENTITY if recorded.get(k) != stats.get(k)}
+        if diff:
+            return None, None, None, (f"the plan of this run differs from the one profiled in profiles/{rnd}_pmc_summary.json "
+                                      f"(recorded, now): {diff} - counters not printed, profile again")
+        note = None
+        if recorded.get("kernel_sources") not in (None, kernel_sources_digest()):
+            note = "the kernel sources changed since the counters were collected (same plan)"
+        onchip = None
+        try:
+            with open(os.path.join(REPO, "profiles", f"{rnd}_onchip_summary.json")) as fh:
+                onchip = json.load(fh)[key]
+        except (OSError, KeyError, ValueError):
+            pass
+        src = f"profiles/{rnd}_pmc_summary.json [{rnd}_{key}] (rocprofv3 --pmc, separate passes, launches of the same length)"
+        return (2.0 * fetch + write) * 1024.0, onchip, src, note
+    return None, None, None, None
+
+
+def timed_steps(call, steps_per_call, min_ms, sync):
+    """``call(k)`` enqueues k steps.  One settled call sizes the number of repetitions so that the timed region lasts
+    >= min_ms; returns (seconds per step, calls)."""
+    call(steps_per_call)
+    sync()
+    t0 = time.perf_counter()
+    call(steps_per_call)
+    sync()
+    est = max(time.perf_counter() - t0, 1e-7)
+    calls = int(min(max(1, np.ceil(min_ms * 1e-3 / est)), 100000))
+    for attempt in range(3):
+        t0 = time.perf_counter()
+        for _ in range(calls):
+            call(steps_per_call)
+        sync()
+        total = time.perf_counter() - t0
+        if total >= min_ms * 1e-3 or attempt == 2:
+            break
+        calls = int(min(np.ceil(1.15 * calls * min_ms * 1e-3 / max(total, 1e-7)), 100000))
+    return total / (calls * steps_per_call), calls
+
+
+def contract_roofline(ne, nn, s_per_step):
+    """algorithmic bytes per step 16*Ne + 216*Nn against the nominal HBM peak."""
+    b_alg = 16 * ne + 216 * nn
+    return {"algorithmic_bytes_per_step": b_alg, "achieved_GBps": b_alg / s_per_step / 1e9,
+            "frac": b_alg / s_per_step / HBM_PEAK}
+
+
+def cache_exceeding_leg(mesh38, device, min_ms):
+    """BASELINE.json's 8.2M-tet beam on ONE GPU (the point that exceeds the Infinity Cache): 2048
+    blocks, two per CU, one launch of the fused kernel per step."""
+    t0 = time.perf_counter()
+    sol, lay, _, dt = build_rank_solver(mesh38, 1, 0, device)
+    setup_s = time.perf_counter() - t0
+    ne, nn = len(lay.cells_local), len(lay.nodes)
+    res = sol.resident_kernel_info()
+    sol.time_steps(300)                                   # settle the clocks on this path
+    est = sol.time_steps(200) / 200.0                     # ms per step
+    short_steps = 1000
+    short = sol.time_steps(short_steps) / short_steps
+    n = int(min(max(200, np.ceil(min_ms / max(est, 1e-6))), 200000))
+    ms = sol.time_steps(n)
+    s_step = ms * 1e-3 / n
+    stats = sol.plan_stats()
+    sol.synchronize()
+    sol.close()
+    key = ("resident" if res["capable"] else "fused") + "38"
+    out = {"workload": f"synthetic 25n x n x n Kuhn-tet beam: {ne} tets, {nn} nodes, ONE partition on one GPU, fp64, dt={dt:.6e}",
+           "kernel": "persistent_steps_kernel<false,false>" if res["capable"] else "fused_step_kernel<false> (one launch per step)",
+           "ms_per_step": 1e3 * s_step, "steps_timed": n, "element_updates_per_s": ne / s_step,
+           "short_region": {"ms_per_step": short, "steps": short_steps}, "setup_seconds": setup_s, "plan": stats}
+    out["roofline"] = contract_roofline(ne, nn, s_step)
+    traffic, onchip, src, note = committed_counters(key, stats)
+    if traffic is not None:
+        out["roofline"].update(traffic=traffic, traffic_source=src,
+                               hbm_measured={"GBps": traffic / s_step / 1e9, "frac_of_peak": traffic / s_step / HBM_PEAK,
+                                             "traffic_over_algorithmic": traffic / out["roofline"]["algorithmic_bytes_per_step"]})
+    if onchip is not None:
+        out["roofline"]["onchip"] = {k: onchip[k] for k in ("valu_busy", "lds_busy", "lds_bank_conflict_share",
+                                                          "wave_wait_share", "wave_issue_stall_share") if k in onchip}
+    if note:
+        out["roofline"]["counters_note"] = note
+    return out
+
+
+def per_gpu_of_8_leg(mesh38, device, min_ms):
+    """What ONE GPU of BASELINE.json's configs[3] / configs[4] does per step: rank 3 of the 8 x-slabs of the 8.2M-tet beam
+    (an interior slab: two interfaces, 3042 shared nodes), on one GPU, through every route a step can take -
+      plain          exchange-free resident steps (what a predicted window runs between predictor calls);
+      peer_loopback  saa_step_peer with loop-back neighbours (saa_peer_attach_loopback: push, stamped entries, rank-ordered
+                     sum all run; the delivery is local memory instead of xGMI);
+      rccl           saa_step_synced with a ONE-rank RCCL communicator: fused kernel -> ncclAllReduce -> finish kernel,
+                     enqueued one by one (eager) and as replayed HIP graphs of three steps (graph);
+      sync_avoiding  windows of 3000 predicted steps, each preceded by the native predictor call at 9126 inputs (seeded
+                     random weights: the cost does not depend on them) - Online_predictor.py:277-318.
+    `projected_8gpu`: all tets of the beam (8 230 800) / that step time, i.e. what 8 GPUs would deliver if the exchange between them cost
+    what it costs inside one (no xGMI latency, no skew between ranks)."""
+    import torch
+
+    from synchronization_avoiding_algorithms_amd import predictor as pr
+
+    world, rank, ne_total = 8, 3, len(mesh38.tets)
+    dev = torch.device("cuda", device)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    t0 = time.perf_counter()
+    sol, lay, gshared, dt = build_rank_solver(mesh38, world, rank, device)
+    setup_s = time.perf_counter() - t0
+    sol.set_stream(stream)
+    ne, nn, nsh = len(lay.cells_local), len(lay.nodes), len(lay.shared_local)
+    res = sol.resident_kernel_info()
+    spl = res["steps_per_launch"] if res["capable"] else 100
+    out = {"workload": f"rank {rank} of {world} x-slabs of the synthetic 25n x n x n beam of {ne_total} tets: {ne} tets, {nn} nodes, "
+                       f"{nsh} shared nodes ({3 * nsh} predicted dofs), all-reduce buffer {3 * len(gshared)} doubles",
+           "resident": bool(res["capable"]), "setup_seconds": setup_s, "plan": sol.plan_stats(), "routes": {}}
+
+    def route(name, s_step, **extra):
+        out["routes"][name] = dict({"us_per_step": 1e6 * s_step, "element_updates_per_s_this_gpu": ne / s_step,
+                                    "contract_frac": contract_roofline(ne, nn, s_step)["frac"]}, **extra)
+
+    sol.step(4 * spl)  # clocks settle over the first tens of milliseconds of load
+    s, calls = timed_steps(sol.step, spl, min_ms, sol.synchronize)
+    route("plain", s, calls=calls, steps_per_call=spl)
+    sol.peer_attach_loopback(2)
+    s, calls = timed_steps(sol.step_peer, spl, min_ms, sol.synchronize)
+    route("peer_loopback", s, calls=calls, steps_per_call=spl,
+          note="every shared node has one imaginary co-holder living in this rank's own inbox")
+    sol.close()
+
+    sol, lay, gshared, dt = build_rank_solver(mesh38, world, rank, device)
+    sol.set_stream(stream)
+    iface = torch.zeros(3 * len(gshared), dtype=torch.float64, device=dev)
+    sol.set_interface_buffer(iface)
+    sol.comm_init(sol.comm_unique_id(), 0, 1)
+    for name, flag in (("rccl_eager", 0), ("rccl_graph", 1)):
+        sol.set_option("synced_graph", flag)
+        s, calls = timed_steps(sol.step_synced, 300, min_ms, sol.synchronize)
+        route(name, s, calls=calls, steps_per_call=300,
+              note="one-rank communicator: the collective is as cheap as it gets, what is measured is the launch route")
+    # sync-avoiding windows: predictor call + 3000 predicted steps, history recorded by the step kernels
+    n_p, n_f, n_s, hid = 20, 20, 150, 50
+    warm, win, width = n_p * n_s, n_f * n_s, 3 * nsh
+    windows = int(min(max(3, np.ceil(min_ms * 1e-3 / (win * out["routes"]["plain"]["us_per_step"] * 1e-6))), 40))
+    torch.manual_seed(1)
+    model = pr.LSTM_encoder_decoder(width, hid).to(dev).eval()
+    hist = torch.zeros((warm + windows * win, width), dtype=torch.float64, device=dev)
+    zero = np.zeros(sol.n_dof)
+    sol.set_state(zero, zero, 0.0)
+    sol.set_option("synced_graph", 0)
+    sol.step_synced(warm, hist, 0)            # the synchronised warm-up records the history the first prediction reads
+    sol.synchronize()
+    a = float(hist[:warm].abs().max()) * 1.05 + 1e-30
+    nat = pr.NativePredictor(model, n_p, n_f, n_s, device)
+    table = nat.predict(warm, hist, a, -a).clone()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    torch.cuda.synchronize(dev)
+    ev[0].record()
+    for _ in range(10):
+        nat.predict(warm, hist, a, -a, table)
+    ev[1].record()
+    torch.cuda.synchronize(dev)
+    pred_ms = ev[0].elapsed_time(ev[1]) / 10
+    i = warm
+    sol.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(windows):
+        nat.predict(i, hist, a, -a, table)
+        sol.step_predicted(win, table, 0, hist, i)
+        i += win
+    sol.synchronize()
+    torch.cuda.synchronize(dev)
+    s = (time.perf_counter() - t0) / (windows * win)
+    finite = bool(torch.isfinite(hist[-1]).all().item())
+    route("sync_avoiding", s, windows=windows, steps_per_window=win, predictor_ms_per_window=pred_ms,
+          predictor_share=pred_ms * 1e-3 / (s * win), state_finite=finite,
+          note="per window: saa_predictor_predict (four launches) + saa_step_predicted(3000); no exchange of any kind")
+    nat.close()
+    sol.close()
+    out["projected_8gpu"] = {
+        "element_updates_per_s": {k: ne_total / (v["us_per_step"] * 1e-6) for k, v in out["routes"].items() if k != "plain"},
+        "assumptions": "all 8 ranks step like this interior slab (the two end slabs have one interface and are not slower: "
+                       "profiles/r03_rank_survey.txt); the exchange between GPUs costs what it costs inside one - local "
+                       "memory latency instead of xGMI's (tools/peer_latency.py: +0.2 us per step at 1 us delivery time, "
+                       "+0.5 at 2 us), a one-rank all-reduce instead of an 8-rank ring; no skew between ranks.  A "
+                       "projection from one-GPU measurements, NOT a measurement on 8 GPUs"}
+    return out
+
+
+def unstructured_leg(n, device, min_ms):
+    """The 1M-tet box meshed WITHOUT any lattice: a Delaunay triangulation of random points (mesh.delaunay_beam), the
+    class of mesh the reference's own Gmsh input belongs to (Mesh_info/beam_US.geo:2-16).  Same material, load, clamp."""
+    t0 = time.perf_counter()
+    mesh = bench_mesh(n, "delaunay")
+    mesh_s = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    sol, lay, _, dt = build_rank_solver(mesh, 1, 0, device)
+    setup_s = time.perf_counter() - t0
+    ne, nn = len(mesh.tets), len(mesh.points)
+    res = sol.resident_kernel_info()
+    spl = res["steps_per_launch"] if res["capable"] else 100
+    sol.time_steps(4 * spl)
+    est = sol.time_steps(2 * spl) / (2 * spl)
+    n_steps = int(min(max(2 * spl, np.ceil(min_ms / max(est, 1e-6) / spl) * spl), 2000000))
+    s_step = sol.time_steps(n_steps) * 1e-3 / n_steps
+    stats = sol.plan_stats()
+    sol.synchronize()
+    sol.close()
+    return {"workload": f"Delaunay triangulation of {nn} random points in the 25 x 1 x 1 box (boundary points on a grid of "
+                        f"the mean spacing): {ne} tets, one partition, fp64, dt={dt:.6e}",
+            "kernel": "persistent_steps_kernel<false,false>" if res["capable"] else "fused_step_kernel<false>",
+            "ms_per_step": 1e3 * s_step, "steps_timed": n_steps, "element_updates_per_s": ne / s_step,
+            "roofline": contract_roofline(ne, nn, s_step), "lds_conflict_factor": stats["lds_conflict_factor"],
+            "lds_atomic_conflict_factor": stats["lds_atomic_conflict_factor"], "plan": stats,
+            "mesh_seconds": mesh_s, "setup_seconds": setup_s}
 
 
 def launch_ranks(args):
@@ -575,23 +837,124 @@ def launch_ranks(args):
         raise SystemExit(rc if rc != 0 else 4)
 
 
-def onchip_block(key, us_per_step, ne_total):
-    """What bounds the kernel on the chip, from the committed PMC passes and in-kernel stamps of the same kernel and mesh
-    (profiles/r03_onchip_summary.json, written by tools/onchip_summary.py from rocprofv3 --pmc runs of this command)."""
-    try:
-        with open(ONCHIP_SUMMARY) as fh:
-            rec = json.load(fh)[key]
-    except (OSError, KeyError, ValueError):
-        return None
-    out = {k: rec[k] for k in ("valu_busy", "lds_busy", "lds_bank_conflict_share", "barrier_wait_share",
-                               "wave_wait_share", "wave_issue_stall_share") if k in rec}
-    if "fp64_flop_per_step" in rec:  # executed fp64 flops (element copies included), counted by the SQ
-        flops = rec["fp64_flop_per_step"] / (us_per_step * 1e-6)
-        out.update(fp64_flops_per_s=flops, frac_of_fp64_vector_peak=flops / FP64_VECTOR_PEAK,
-                   fp64_vector_peak=FP64_VECTOR_PEAK, fp64_flop_per_step=rec["fp64_flop_per_step"],
-                   fp64_flop_per_element_update=rec["fp64_flop_per_step"] / ne_total)
-    out["source"] = rec.get("source", "profiles/r03_onchip_summary.json")
-    return out
+def single_gpu_legs(args, legs, put, sol, stats, n, ne_total, nn_total, device):
+    """The extra legs of the N = 1 line, each inside the run's budget: roofline of the headline kernel, the per-GPU
+    workload of configs[3] / [4], the cache-exceeding point, the unstructured mesh, the predictor, the CPU baseline."""
+    wanted = {"roofline", "per_gpu_of_8", "cache_exceeding", "unstructured", "predictor", "cpu_baseline"}
+    if args.legs not in ("all", ""):
+        wanted = set() if args.legs == "none" else {w.strip() for w in args.legs.split(",")}
+    if args.no_cpu_baseline:
+        wanted.discard("cpu_baseline")
+
+    def run(leg, need_s, fn, key=None):
+        """One leg: skipped when not wanted or when less than `need_s` seconds of the budget are left; a failure is
+        reported in the line and never costs the headline."""
+        if leg not in wanted:
+            legs.skip(leg, "not requested (--legs / --no-cpu-baseline)")
+            return
+        if legs.left() < need_s:
+            legs.skip(leg, f"{legs.left():.0f} s of the budget left, needs ~{need_s:.0f}")
+            return
+        legs.begin(leg)
+        try:
+            value = fn()
+            if key is not None:
+                put(key, value)
+            legs.end(leg)
+        except Exception as exc:  # noqa: BLE001
+            put(key or leg, {"error": repr(exc)[:500]})
+            legs.end(leg, "failed")
+
+    def roofline():
+        # the dominant (only) kernel, HIP events on the kernel's own stream.  One launch of the resident kernel advances
+        # `spl` steps (one launch = spl * Ne element-updates); without it (plan does not fit LDS / not all workgroups
+        # co-resident) one launch of the fused kernel is one step
+        res = sol.resident_kernel_info()
+        spl = res["steps_per_launch"] if res["capable"] else 1
+        sol.time_steps(2 * spl if spl > 1 else 200)  # settle the clocks on this very path
+        short_launches = 12 if spl > 1 else 3000
+        short_ms = sol.time_steps(short_launches * spl)
+        est = short_ms / short_launches                                    # ms per launch
+        launches = int(min(max(short_launches, np.ceil(max(args.min_timed_ms, 1000.0) / est)), 2000000 // spl))
+        ms = sol.time_steps(launches * spl)
+        b_alg = 16 * ne_total + 216 * nn_total
+        dur_s = ms * 1e-3 / (launches * spl)  # per step
+        achieved = b_alg / dur_s
+        roof = {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK, "traffic": None,
+                "kernel": "persistent_steps_kernel<false,false>" if spl > 1 else "fused_step_kernel<false>",
+                "steps_per_launch": spl, "launches_timed": launches, "avg_launch_us": 1e3 * ms / launches,
+                "us_per_step": 1e6 * dur_s, "timed_region_ms": ms,
+                "short_region": {"launches": short_launches, "avg_launch_us": 1e3 * short_ms / short_launches,
+                                 "us_per_step": 1e3 * short_ms / (short_launches * spl),
+                                 "frac": b_alg / (short_ms * 1e-3 / (short_launches * spl)) / HBM_PEAK,
+                                 "note": "the ~90 ms region earlier rounds quoted; the figures of this object come from "
+                                         "the >= 1 s region (the chip settles at a lower clock under sustained load)"},
+                "algorithmic_bytes_per_step": b_alg, "algorithmic_bytes_per_launch": b_alg * spl,
+                "algorithmic_bytes_per_element_update": b_alg / ne_total,
+                "note": "achieved / frac are the CONTRACT figure: algorithmic bytes (SURVEY.md section 8(d): what a kernel "
+                        "that re-reads the partition every step must move) per second against the HBM peak - an "
+                        "equivalent bandwidth, not the kernel's HBM traffic.  What it moves is `traffic` / `hbm_measured`; "
+                        "what bounds it is `bound` / `onchip`."}
+        key = (f"resident{n}" if spl > 1 else f"fused{n}") + {"structured": "", "jittered": "_jittered",
+                                                               "delaunay": "_delaunay"}[args.mesh]
+        traffic, onchip, src, note = committed_counters(key, stats)
+        if traffic is not None:
+            roof["traffic"] = traffic
+            roof["traffic_source"] = src
+            hbm = traffic / (dur_s * spl)
+            roof["hbm_measured"] = {"GBps": hbm / 1e9, "frac_of_peak": hbm / HBM_PEAK,
+                                    "traffic_over_algorithmic": traffic / (b_alg * spl)}
+        if note:
+            roof["counters_note"] = note
+        if onchip is not None:
+            oc = {k: onchip[k] for k in ("valu_busy", "lds_busy", "lds_bank_conflict_share", "barrier_wait_share",
+                                         "wave_wait_share", "wave_issue_stall_share") if k in onchip}
+            if "fp64_flop_per_step" in onchip:  # executed fp64 flops (element copies included), counted by the SQ
+                flops = onchip["fp64_flop_per_step"] / dur_s
+                oc.update(fp64_flops_per_s=flops, frac_of_fp64_vector_peak=flops / FP64_VECTOR_PEAK,
+                          fp64_vector_peak=FP64_VECTOR_PEAK, fp64_flop_per_step=onchip["fp64_flop_per_step"],
+                          fp64_flop_per_element_update=onchip["fp64_flop_per_step"] / ne_total)
+            oc["source"] = onchip.get("source")
+            roof["onchip"] = oc
+            if roof.get("hbm_measured", {}).get("frac_of_peak", 1.0) < 0.5:
+                # the counters say what the limiter is: name it where a reader looks first
+                roof["bound"] = "on-chip (fp64 vector issue + LDS pipe; the partition is LDS-resident, HBM is not the limiter)"
+                roof["contract_bound"] = "hbm"
+        copy_bw = measured_copy_bandwidth(device)
+        roof["measured_copy_GBps"] = copy_bw / 1e9
+        roof["measured_copy_kernel"] = "saa_device_copy_bandwidth: one 16-byte element per thread, 1 GiB -> 1 GiB, 10 launches"
+        roof["frac_of_measured_copy"] = achieved / copy_bw
+        return roof
+
+    run("roofline", 10.0, roofline, "roofline")
+    sol.close()
+    mesh38 = {}
+
+    def get38():
+        if "m" not in mesh38:
+            from synchronization_avoiding_algorithms_amd.mesh import structured_beam
+
+            mesh38["m"] = structured_beam(args.big_refine)
+        return mesh38["m"]
+
+    if args.mesh == "structured" and not args.refine:
+        # the other BASELINE configurations, as far as one GPU can carry them (the driver has no 8-GPU node every round)
+        run("per_gpu_of_8", 75.0, lambda: per_gpu_of_8_leg(get38(), device, args.min_timed_ms), "per_gpu_of_8")
+        run("cache_exceeding", 110.0, lambda: cache_exceeding_leg(get38(), device, args.min_timed_ms), "cache_exceeding")
+        mesh38.clear()
+        run("unstructured", 120.0, lambda: unstructured_leg(n, device, args.min_timed_ms), "unstructured")
+    else:
+        for leg in ("per_gpu_of_8", "cache_exceeding", "unstructured"):
+            legs.skip(leg, "only with the default mesh (--mesh structured, no --refine)")
+    run("predictor", 60.0, lambda: predictor_leg(device), "predictor")
+
+    def cpu():
+        base, parity = cpu_baseline_and_parity(n if args.mesh == "structured" else 10, legs=legs)
+        put("parity", parity)
+        return base
+
+    run("cpu_baseline", 45.0, cpu, "cpu_baseline")
 
 
 def main():
@@ -600,8 +963,9 @@ def main():
     ap.add_argument("--steps", type=int, default=5000)
     ap.add_argument("--warmup", type=int, default=500)
     ap.add_argument("--refine", type=int, default=0, help="override mesh refinement n (25n x n x n cubes)")
-    ap.add_argument("--mesh", default="structured", choices=["structured", "jittered"],
-                    help="jittered: the same beam with moved nodes and random numbering (an unstructured mesh)")
+    ap.add_argument("--mesh", default="structured", choices=["structured", "jittered", "delaunay"],
+                    help="jittered: the same beam with moved nodes and random numbering; delaunay: the same box meshed by a "
+                         "Delaunay triangulation of random points (an unstructured mesh without any lattice)")
     ap.add_argument("--block-nodes", type=int, default=0)
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -629,8 +993,17 @@ def main():
     ap.add_argument("--same-device", action="store_true",
                     help="rehearsal on a one-GPU box: every rank uses cuda:0 (needs --backend gloo)")
     ap.add_argument("--preflight", action="store_true", help=argparse.SUPPRESS)
-    ap.add_argument("--min-timed-ms", type=float, default=50.0,
-                    help="the timed call of --steps steps is repeated until the timed region lasts at least this long")
+    ap.add_argument("--force-preflight", action="store_true", help=argparse.SUPPRESS)  # tests: preflight with --same-device
+    ap.add_argument("--force-rccl-leg", action="store_true", help=argparse.SUPPRESS)   # tests: the RCCL leg on gloo
+    ap.add_argument("--min-timed-ms", type=float, default=1000.0,
+                    help="the timed call of --steps steps is repeated until the timed region lasts at least this long; "
+                         "the legs of the N = 1 line time regions of the same length")
+    ap.add_argument("--big-refine", type=int, default=38,
+                    help="refinement n of the 8-GPU beam whose rank 3 of 8 / whole mesh the per_gpu_of_8 / cache_exceeding "
+                         "legs of the N = 1 line step (38: BASELINE.json's 8.2M tets; smaller values are for tests)")
+    ap.add_argument("--legs", default="all",
+                    help="N = 1: comma-separated extra legs to run (roofline, per_gpu_of_8, cache_exceeding, unstructured, "
+                         "predictor, cpu_baseline), or all / none")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -649,7 +1022,7 @@ def main():
     # child process, so that a fault there costs the child, not the benchmark (which then takes the RCCL all-reduce)
     exchange = "torch" if args.torch_exchange else args.exchange
     peer_ok = True
-    if world > 1 and exchange == "auto" and (not args.same_device or os.environ.get("SAA_BENCH_FORCE_PREFLIGHT")):
+    if world > 1 and exchange == "auto" and (not args.same_device or args.force_preflight):
         limit = min(90.0, 0.25 * max(legs.left(), 0.0))
         legs.begin("preflight")
         peer_ok = run_preflight(args, world, limit)
@@ -685,12 +1058,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def build_and_time(how):
+    def build_and_time(how, synced_graph=None):
         """Partition solver with the given transport, W warm-up and K timed steps; ``ok`` is False on any rank if a
         wait inside a kernel gave up (peer exchange: a neighbour's values never arrived)."""
         part = PartitionedSolver(mesh.points, mesh.tets, mesh.triangles, epart, rank, world, E=E, nu=NU, rho=RHO,
                                  fz=FZ, alpha=ALPHA, gamma=GAMMA, device=local_rank, block_nodes=args.block_nodes,
                                  threads=args.threads, exchange=how)
+        if synced_graph is not None and hasattr(part.solver, "set_option"):
+            part.solver.set_option("synced_graph", synced_graph)  # saa_step_synced: replayed graphs / eager launches
         part.step_synced(args.warmup)  # world == 1: plain steps; else one exchange of shared-node forces per step
         # The timed call is `part.step_synced(args.steps)`.  Which kernels that runs depends on the call length (calls
         # of >= 8 steps take the resident kernel), so exactly that call is issued once more untimed - the first launch
@@ -770,7 +1145,7 @@ def main():
                                         "ncclAllReduce issued from C++ (saa_step_synced)",
                                 "torch": f"all-reduce of {3 * len(gshared)} fp64 shared-node forces every step, "
                                          f"torch.distributed ({args.backend})"}[part.exchange],
-                   "plan": stats},
+                   "plan": stats, "kernel_sources": kernel_sources_digest()},
     }
     if world > 1:
         out["config"]["peer_preflight_rank0"] = preflight  # child-process trial of the peer exchange (None: not run)
@@ -787,7 +1162,7 @@ def main():
     # N > 1: the same partitions in sync-avoiding mode (BASELINE.json configs[4]; Online_predictor.py:251-318).
     rccl_wanted = (world > 1 and not args.no_rccl_leg and
                    ((part.exchange == "peer" and args.backend == "nccl" and not args.same_device) or
-                    bool(os.environ.get("SAA_BENCH_FORCE_RCCL_LEG"))))
+                    args.force_rccl_leg))
     rccl_reserve = 60.0 if rccl_wanted else 0.0
     if world > 1 and not args.no_sync_avoiding:
         # what the leg needs besides training: the recorded run, the predictor's capture, the windows (~20 s at N = 8)
@@ -803,82 +1178,8 @@ def main():
             legs.end("sync_avoiding")
 
     if world == 1:
-        legs.begin("roofline")
-        # roofline of the dominant (only) kernel: HIP events on the kernel's own stream
-        # one launch of the resident kernel advances `spl` steps (one launch = spl * Ne element-updates); without it
-        # (plan does not fit LDS / not all workgroups co-resident) one launch of the fused kernel is one step
-        res = sol.resident_kernel_info()
-        spl = res["steps_per_launch"] if res["capable"] else 1
-        launches = 12 if spl > 1 else 3000
-        sol.time_steps(2 * spl if spl > 1 else 200)  # settle the clocks on this very path
-        ms = sol.time_steps(launches * spl)
-        b_alg = 16 * ne_total + 216 * nn_total
-        dur_s = ms * 1e-3 / (launches * spl)  # per step
-        achieved = b_alg / dur_s
-        roof = {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK, "traffic": None,
-                "kernel": "persistent_steps_kernel<false,false>" if spl > 1 else "fused_step_kernel<false>",
-                "steps_per_launch": spl, "launches_timed": launches, "avg_launch_us": 1e3 * ms / launches,
-                "us_per_step": 1e6 * dur_s,
-                "algorithmic_bytes_per_step": b_alg, "algorithmic_bytes_per_launch": b_alg * spl,
-                "algorithmic_bytes_per_element_update": b_alg / ne_total,
-                "note": "achieved / frac are the CONTRACT figure: algorithmic bytes (SURVEY.md section 8(d): what a kernel "
-                        "that re-reads the partition every step must move) per second - an equivalent bandwidth, not the "
-                        "kernel's HBM traffic.  What it moves is `traffic` / `hbm_measured`; what bounds it is `onchip` "
-                        "(`effective_limiter`)."}
-        # HBM traffic per launch from the committed PMC passes of this same kernel and mesh (tools/pmc_collect.sh:
-        # rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes, nothing else enabled; KiB units; FETCH_SIZE
-        # doubled: gfx950 counts 64 B per 128-B request, MI355X_MICROARCH.md "HBM").  Only for the meshes that were
-        # profiled (n = 19 resident, n = 38 fused); otherwise null.
-        key = (f"resident{n}" if spl > 1 else f"fused{n}") + ("_jittered" if args.mesh == "jittered" else "")
-        for rnd in ("r03", "r02"):
-            try:
-                with open(os.path.join(REPO, "profiles", f"{rnd}_pmc_summary.json")) as fh:
-                    pmc = json.load(fh)
-                fetch = pmc[f"{rnd}_{key}:FETCH_SIZE"]["mean_per_dispatch"]
-                write = pmc[f"{rnd}_{key}:WRITE_SIZE"]["mean_per_dispatch"]
-            except (OSError, KeyError, ValueError):
-                continue
-            roof["traffic"] = (2.0 * fetch + write) * 1024.0
-            roof["traffic_source"] = (f"profiles/{rnd}_pmc_summary.json (rocprofv3 --pmc, separate passes, launches of "
-                                      "the same length)")
-            hbm = roof["traffic"] / (dur_s * spl)
-            roof["hbm_measured"] = {"GBps": hbm / 1e9, "frac_of_peak": hbm / HBM_PEAK,
-                                    "traffic_over_algorithmic": roof["traffic"] / (b_alg * spl)}
-            break
-        onchip = onchip_block(key, 1e6 * dur_s, ne_total)
-        if onchip is not None:
-            roof["onchip"] = onchip
-            roof["effective_limiter"] = ("on-chip: fp64 vector issue and the LDS pipe, each busy about two thirds of the "
-                                         "time, plus the barrier-separated phases that keep them from overlapping "
-                                         "(not HBM: see hbm_measured)")
-        copy_bw = measured_copy_bandwidth(local_rank)
-        roof["measured_copy_GBps"] = copy_bw / 1e9
-        roof["measured_copy_kernel"] = "saa_device_copy_bandwidth: one 16-byte element per thread, 1 GiB -> 1 GiB, 10 launches"
-        roof["frac_of_measured_copy"] = achieved / copy_bw
-        put("roofline", roof)
-        legs.end("roofline")
-        if legs.left() < 60.0:
-            legs.skip("predictor", f"{legs.left():.0f} s of the budget left")
-        else:
-            legs.begin("predictor")
-            try:
-                put("predictor", predictor_leg(local_rank))
-                legs.end("predictor")
-            except Exception as exc:  # the headline and its roofline stand whatever happens here
-                put("predictor", {"error": repr(exc)})
-                legs.end("predictor", "failed")
-        if args.no_cpu_baseline:
-            legs.skip("cpu_baseline", "--no-cpu-baseline")
-        elif legs.left() < 45.0:
-            legs.skip("cpu_baseline", f"{legs.left():.0f} s of the budget left")
-        else:
-            legs.begin("cpu_baseline")
-            base, parity = cpu_baseline_and_parity(n if args.mesh == "structured" else 10, legs=legs)
-            put("cpu_baseline", base)
-            put("parity", parity)
-            legs.end("cpu_baseline")
-    sol.close()
+        single_gpu_legs(args, legs, put, sol, stats, n, ne_total, nn_total, local_rank)
+    sol.close()  # (idempotent: the N = 1 legs have closed it already to make room for their own solvers)
     # N > 1: BASELINE.json configs[3] names the RCCL all-reduce as the per-step exchange.  When `value` above was
     # measured with the peer exchange, the same partitions are stepped once more with ncclAllReduce issued from C++
     # (saa_step_synced) and reported next to it.
@@ -895,8 +1196,7 @@ def main():
             # measured and leaves with a NON-ZERO status, so that the hang is seen
             put("rccl_allreduce", {"value": None, "exchange": f"timed out after {limit:.0f} s"})
             legs.begin("rccl_allreduce", limit_s=limit)
-            if os.environ.get("SAA_BENCH_TEST_STALL_RCCL"):  # tests only: a collective that never returns
-                time.sleep(3600)
+            test_hook("rccl_leg")
             k_r, w_r = min(args.steps, 2000), min(args.warmup, 200)
             args_steps, args_warmup = args.steps, args.warmup
             args.steps, args.warmup = k_r, w_r
@@ -904,10 +1204,9 @@ def main():
             # has run before), then the same steps as replayed HIP graphs of three steps each (saa_step_synced's default);
             # the first figure is in the line before the second route is tried
             res, ok_any = {}, False
-            for route, env in (("eager", "0"), ("graph", "1")):
-                os.environ["SAA_SYNCED_GRAPH"] = env
+            for route, env in (("eager", 0), ("graph", 1)):
                 try:
-                    part_r, elapsed_r, ok_r = build_and_time("rccl" if args.backend == "nccl" else "torch")
+                    part_r, elapsed_r, ok_r = build_and_time("rccl" if args.backend == "nccl" else "torch", synced_graph=env)
                     how = part_r.exchange
                     part_r.close()
                 except Exception as e:  # noqa: BLE001 - reported, never fatal for the headline line
@@ -923,16 +1222,12 @@ def main():
                                                 "value = the faster of the two launch routes"))
                 if how != "rccl":  # (the torch transport has no graph route)
                     break
-            os.environ.pop("SAA_SYNCED_GRAPH", None)
             args.steps, args.warmup = args_steps, args_warmup
             legs.end("rccl_allreduce", "done" if ok_any else "failed")
     legs.emit(final=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    if os.environ.get("SAA_BENCH_DUMP_MAPS"):  # profiling runs: lets a crash in an exit handler be attributed
-        with open("/proc/self/maps") as src, open(os.environ["SAA_BENCH_DUMP_MAPS"], "w") as dst:
-            dst.write(src.read())
 
 
 if __name__ == "__main__":

@@ -39,10 +39,9 @@ def main():
     args = ap.parse_args()
     if args.epochs <= 0:  # the reference's schedule: until the decayed rate reaches lr_min (Model_training.py:65)
         args.epochs = None
-    if args.same_device and not args.sequential_training:
-        # ranks sharing one GPU: graph replays of two processes on one device get in each other's way (2x slower than
-        # eager launches); with one GPU per rank the graphed optimiser step is 3.7x faster and stays on
-        os.environ.setdefault("SAA_TRAIN_GRAPH", "0")
+    # ranks sharing one GPU: graph replays of two processes on one device get in each other's way (2x slower than eager
+    # launches); with one GPU per rank the graphed optimiser step is 3.7x faster and stays on
+    train_graph = False if (args.same_device and not args.sequential_training) else None
 
     import torch
     import torch.distributed as dist
@@ -75,7 +74,7 @@ def main():
         if not args.sequential_training or turn == rank:
             path, tl, vl = training.train_rank_model(args.out, rank, device=f"cuda:{local}", hidden_size=args.hidden_size,
                                                      filter_size=args.filter_size, num_epochs=args.epochs, seed=rank,
-                                                     verbose=True)
+                                                     verbose=True, graph=train_graph)
         barrier()
     t2 = time.time()
     _, modeled, _ = drivers.online_predictor(mesh, args.steps, 1, args.out, rank, world, device=local,

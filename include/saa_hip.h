@@ -81,10 +81,12 @@ typedef struct saa_plan_stats {
   int64_t n_items;          /* work items (pairs of face-adjacent elements, single elements, idle slots of the packing) */
   int64_t n_pairs;          /* items that hold two elements */
   int64_t n_by_construction; /* item slots in half-waves that are clash-free by construction (pattern classes) */
+  int32_t n_renumbered;     /* blocks whose nodes took another order than the plan's first choice (axis order / pseudo-lattice) */
+  int32_t reserved;
 } saa_plan_stats;
 
 const char *saa_last_error(void);
-/* Library / ABI version; bumps when this header changes (2: peer exchange and resident-kernel entry points; 3: loop-back attach; 4: partitioner and set-up kernels; 5: deterministic mode; 6: copy-bandwidth aid; 7: saa_plan_stats grew; 8: saa_predictor_*, saa_topology_*). */
+/* Library / ABI version; bumps when this header changes (2: peer exchange and resident-kernel entry points; 3: loop-back attach; 4: partitioner and set-up kernels; 5: deterministic mode; 6: copy-bandwidth aid; 7: saa_plan_stats grew; 8: saa_predictor_*, saa_topology_*; 9: saa_set_option, saa_plan_stats.n_renumbered). */
 int32_t saa_abi_version(void);
 
 /* Element partition, one part per rank / GPU: the role of `_, epart = part_mesh_kway(size, eptr, eind)` (mgmetis /
@@ -240,6 +242,13 @@ int saa_resident_kernel_info(const saa_solver *s, int32_t *capable, int32_t *lds
 /* enable = 0: keep this handle on one launch per step (for callers that know the device is shared with other
  * processes: workgroups of a resident kernel that wait for another process' kernel only advance by time-slicing). */
 int saa_set_resident_kernel(saa_solver *s, int32_t enable);
+/* Run-time options of a handle, by name (the library itself reads no environment variable):
+ *   "synced_graph"    1 (default) / 0: saa_step_synced replays HIP graphs of three steps each / enqueues every kernel and
+ *                     collective itself (the role of the per-step MPI calls of Distributed_tools.py:77-92);
+ *   "wait_timeout_s"  bound, in seconds (default 30), of every in-kernel wait for another workgroup or rank (resident
+ *                     kernel, peer exchange); a wait that gives up is reported as SAA_E_STATE by saa_synchronize.
+ * The reference has no counterpart (an MPI rank that loses its peer hangs, Distributed_tools.py:77-92). */
+int saa_set_option(saa_solver *s, const char *name, double value);
 
 /* Deterministic mode.  The step kernels accumulate the element forces of a node with LDS floating-point atomics, whose
  * order is free: f_int - and with it the trajectory - differs in the last bits from run to run (the same class of

@@ -20,7 +20,7 @@ HEADER = os.path.join(os.path.dirname(_HERE), "include", "saa_hip.h")
 SOURCES = ["saa_plan.cpp", "saa_partition.cpp", "saa_kernels.hip", "saa_setup.hip", "saa_predictor.hip", "saa_topology.hip", "saa_api.cpp"]
 HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics", "-ldl"]
 
-ABI_VERSION = 8  # what saa_abi_version() of a matching library returns (include/saa_hip.h)
+ABI_VERSION = 9  # what saa_abi_version() of a matching library returns (include/saa_hip.h)
 SAA_OK, SAA_E_ARG, SAA_E_HIP, SAA_E_STATE, SAA_E_CAPACITY = 0, -1, -2, -3, -4
 
 
@@ -56,12 +56,12 @@ class PlanStats(C.Structure):
         ("n_elem_copies", C.c_int64), ("n_halo_total", C.c_int64),
         ("lds_bytes", C.c_int32), ("threads", C.c_int32), ("lds_conflict_factor", C.c_double),
         ("lds_atomic_conflict_factor", C.c_double), ("n_items", C.c_int64), ("n_pairs", C.c_int64),
-        ("n_by_construction", C.c_int64),
+        ("n_by_construction", C.c_int64), ("n_renumbered", C.c_int32), ("reserved", C.c_int32),
     ]
 
     def as_dict(self):
         return {name: (float if name.endswith("conflict_factor") else int)(getattr(self, name))
-                for name, _ in self._fields_}
+                for name, _ in self._fields_ if name != "reserved"}
 
 
 _dp = C.POINTER(C.c_double)
@@ -96,6 +96,7 @@ SIGNATURES = {
     "saa_resident_kernel_info": (C.c_int, [_H, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "saa_set_recorder": (C.c_int, [_H, C.c_void_p, C.c_int64, C.c_int32, C.c_int64]),
     "saa_set_resident_kernel": (C.c_int, [_H, C.c_int32]),
+    "saa_set_option": (C.c_int, [_H, C.c_char_p, C.c_double]),
     "saa_set_deterministic": (C.c_int, [_H, C.c_int32]),
     "saa_peer_export": (C.c_int, [_H, C.c_int32, C.POINTER(C.c_uint8), C.POINTER(C.c_int32)]),
     "saa_peer_attach": (C.c_int, [_H, C.c_int32, C.c_int32, C.POINTER(C.c_uint8), C.POINTER(C.c_int32),
@@ -176,13 +177,14 @@ def load():
             pass
     lib = C.CDLL(LIB_PATH)
     lib.saa_abi_version.restype = C.c_int32
-    if os.environ.get("SAA_LIB_PATH") and 6 <= lib.saa_abi_version() < ABI_VERSION:
-        pass  # experiments only (tools/ab.py: an older build next to the current one; newer entry points are missing)
+    old_ok = os.environ.get("SAA_ALLOW_OLD_ABI") == "1"  # set by tools/ab.py only: an older build next to the current one
+    if old_ok and 6 <= lib.saa_abi_version() < ABI_VERSION:
+        pass  # (newer entry points are missing there)
     elif lib.saa_abi_version() != ABI_VERSION:
         raise RuntimeError(f"{LIB_PATH} has ABI version {lib.saa_abi_version()}, this package needs {ABI_VERSION}: "
                            "rebuild it (`python -c 'import __graft_entry__ as g; g.build()'`)")
     for name, (res, args) in SIGNATURES.items():
-        if os.environ.get("SAA_LIB_PATH") and not hasattr(lib, name):
+        if old_ok and not hasattr(lib, name):
             continue
         fn = getattr(lib, name)
         fn.restype = res

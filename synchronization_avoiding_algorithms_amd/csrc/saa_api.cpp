@@ -129,7 +129,9 @@ struct saa_solver {
   hipGraphExec_t sync_graph[3] = {nullptr, nullptr, nullptr};
   hipStream_t sync_graph_stream = nullptr;
   double *sync_graph_iface = nullptr;
-  bool sync_graph_off = false;
+  bool sync_graph_off = false;     // capture or instantiation failed once: eager launches for good
+  bool sync_graph_wanted = true;   // saa_set_option("synced_graph")
+  double wait_timeout_s = 30.0;    // saa_set_option("wait_timeout_s"): bound of every in-kernel wait for other workgroups / ranks
   // resident multi-step kernel (saa_device.h: PersistArgs)
   DevBuf<int32_t> ps_err;
   DevBuf<saa::PeerEntry> ps_entries;  // 2 x 3*n_nodes stamped displacements
@@ -233,6 +235,8 @@ void fill_stats(const saa::Plan &plan, int lds, int threads, saa_plan_stats *out
   out->n_items = plan.n_items;
   out->n_pairs = plan.n_pairs;
   out->n_by_construction = plan.n_by_construction;
+  out->n_renumbered = plan.n_renumbered;
+  out->reserved = 0;
 }
 
 bool build_fitting_plan(int32_t n_nodes, int32_t n_elems, const double *xyz, const int32_t *tets,
@@ -391,7 +395,7 @@ bool persistent_census(saa_solver *s, int lds, int mode) {
 // Entry buffers and capacity check of the resident kernel; failure only disables it.
 void setup_persistent(saa_solver *s) {
   s->ps_capable = false;
-  if (const char *env = std::getenv("SAA_NO_PERSISTENT"))
+  if (const char *env = saa::diag_env("SAA_NO_PERSISTENT"))
     if (env[0] == '1') return;
   const saa::Plan &plan = s->plan;
   const int32_t nb = static_cast<int32_t>(plan.blocks.size());
@@ -403,8 +407,9 @@ void setup_persistent(saa_solver *s) {
   const int lds = saa::persistent_lds_bytes(plan.max_local, plan.max_owned, max_items, max_halo);
   if (lds == 0) return;
   // grid sizing: occupancy query clamped by the scalar-register rule (persistent_max_blocks), then the census below.
-  // SAA_RESIDENT_TRUST_GRID=1 (tests only) skips the first check so that an over-sized grid reaches the census.
-  const char *trust = std::getenv("SAA_RESIDENT_TRUST_GRID");
+  // SAA_RESIDENT_TRUST_GRID=1 (diagnostic build, the census test) skips the first check so that an over-sized grid
+  // reaches the census.
+  const char *trust = saa::diag_env("SAA_RESIDENT_TRUST_GRID");
   const int max_blocks = saa::persistent_max_blocks(s->device, s->threads, lds);
   if (max_blocks <= 0 || (max_blocks < nb && !(trust && trust[0] == '1'))) return;
   const size_t n_entries = 2 * 3 * static_cast<size_t>(plan.n_nodes);
@@ -464,9 +469,8 @@ int try_persistent_steps(saa_solver *s, int32_t nsteps, const double *table_dev,
   if (peer && s->ps_lds_peer == 0) return SAA_OK;
   if (table_dev != nullptr && !s->ps_capable_predict) return SAA_OK;
   int32_t chunk = kPersistChunk;
-  if (const char *env = std::getenv("SAA_PERSIST_CHUNK")) chunk = std::max(kPersistMinSteps, std::atoi(env));
-  double timeout_s = 30.0;
-  if (const char *env = std::getenv("SAA_PEER_TIMEOUT_S")) timeout_s = std::max(1e-7, std::atof(env));
+  if (const char *env = saa::diag_env("SAA_PERSIST_CHUNK")) chunk = std::max(kPersistMinSteps, std::atoi(env));
+  const double timeout_s = s->wait_timeout_s;
   while (*n_done < nsteps) {
     int32_t n = std::min(chunk, nsteps - *n_done);
     if (nsteps - *n_done - n > 0 && nsteps - *n_done - n < kPersistMinSteps) n = nsteps - *n_done;  // no tiny tail
@@ -561,8 +565,7 @@ void launch_force(saa_solver *s, const double *d, double *f) {
 int try_synced_graphs(saa_solver *s, int32_t nsteps, bool wants_hist, int32_t *n_done) {
   *n_done = 0;
   if (s->sync_graph_off || wants_hist || s->rec_traj || s->det || nsteps < 6) return SAA_OK;
-  if (const char *env = std::getenv("SAA_SYNCED_GRAPH"))
-    if (env[0] == '0') return SAA_OK;
+  if (!s->sync_graph_wanted) return SAA_OK;
   const size_t count = 3 * static_cast<size_t>(s->n_global_shared);
   if (s->sync_graph_stream != s->stream || s->sync_graph_iface != s->iface) {  // captured for another stream / buffer
     for (auto &g : s->sync_graph) {
@@ -637,7 +640,7 @@ extern "C" {
 
 const char *saa_last_error(void) { return g_last_error.c_str(); }
 
-int32_t saa_abi_version(void) { return 8; }  // 4: saa_part_mesh_kway, saa_setup_fields; 5: saa_set_deterministic; 6: saa_device_copy_bandwidth; 7: saa_plan_stats grew; 8: saa_predictor_*, saa_topology_*
+int32_t saa_abi_version(void) { return 9; }  // 4: saa_part_mesh_kway, saa_setup_fields; 5: saa_set_deterministic; 6: saa_device_copy_bandwidth; 7: saa_plan_stats grew; 8: saa_predictor_*, saa_topology_*; 9: saa_set_option, saa_plan_stats.n_renumbered
 
 int saa_device_copy_bandwidth(int32_t device, int64_t n_bytes, int32_t reps, double *bytes_per_s) {
   if (!bytes_per_s || n_bytes < 16 || reps < 1) return fail(SAA_E_ARG, "saa_device_copy_bandwidth: bad argument");
@@ -729,7 +732,7 @@ int saa_create(const saa_problem *pb, saa_solver **out) {
   std::vector<int32_t> extra;
   if (pb->n_shared > 0) {
     int32_t per_node = 16;  // 10 is the optimum with local latency (loop-back); xGMI's is longer
-    if (const char *env = std::getenv("SAA_SHARED_NODE_WORK")) per_node = std::max(0, std::atoi(env));
+    if (const char *env = saa::diag_env("SAA_SHARED_NODE_WORK")) per_node = std::max(0, std::atoi(env));
     extra.assign(pb->n_nodes, 0);
     for (int32_t i = 0; i < pb->n_shared; ++i) extra[pb->shared_nodes[i]] = per_node;
   }
@@ -1304,9 +1307,7 @@ static int peer_attach_impl(saa_solver *s, int32_t rank, int32_t world, const ui
   pm.inbox = static_cast<const saa::PeerEntry *>(s->peer_mem);
   pm.parity_stride = per_me * world;
   pm.err = s->px_err.p;
-  double timeout_s = 30.0;
-  if (const char *env = std::getenv("SAA_PEER_TIMEOUT_S")) timeout_s = std::max(1e-7, std::atof(env));
-  pm.timeout_ticks = static_cast<int64_t>(timeout_s * 1e8);  // wall_clock64(): 100 MHz
+  pm.timeout_ticks = static_cast<int64_t>(s->wait_timeout_s * 1e8);  // wall_clock64(): 100 MHz
   pm.rank = rank;
   pm.world = world;
   pm.n_shared = nsh;
@@ -1418,7 +1419,7 @@ int saa_halo_scatter(saa_solver *s, const double *row_dev) {
 int saa_resident_kernel_info(const saa_solver *s, int32_t *capable, int32_t *lds_bytes, int32_t *steps_per_launch) {
   if (!s) return fail(SAA_E_ARG, "saa_resident_kernel_info: null handle");
   int32_t chunk = kPersistChunk;
-  if (const char *env = std::getenv("SAA_PERSIST_CHUNK")) chunk = std::max(kPersistMinSteps, std::atoi(env));
+  if (const char *env = saa::diag_env("SAA_PERSIST_CHUNK")) chunk = std::max(kPersistMinSteps, std::atoi(env));
   if (capable) *capable = s->ps_capable && s->ps_enabled && s->mesh.mass_node && s->mesh.fext_yz ? 1 : 0;
   if (lds_bytes) *lds_bytes = s->ps_lds;
   if (steps_per_launch) *steps_per_launch = chunk;
@@ -1471,6 +1472,27 @@ int saa_set_deterministic(saa_solver *s, int32_t enable) {
   }
   s->det = enable != 0;
   return SAA_OK;
+}
+
+int saa_set_option(saa_solver *s, const char *name, double value) {
+  if (!s || !name) return fail(SAA_E_ARG, "saa_set_option: null argument");
+  const std::string key(name);
+  if (key == "synced_graph") {
+    s->sync_graph_wanted = value != 0.0;
+    return SAA_OK;
+  }
+  if (key == "wait_timeout_s") {
+    if (!(value > 0.0) || value > 3600.0) return fail(SAA_E_ARG, "saa_set_option: wait_timeout_s must be in (0, 3600]");
+    s->wait_timeout_s = std::max(1e-7, value);
+    if (s->px_map.p) {  // attached already: the step kernels read the bound from the device copy of the peer map
+      HIP_TRY(hipSetDevice(s->device));
+      HIP_TRY(hipStreamSynchronize(s->stream));
+      s->peer.timeout_ticks = static_cast<int64_t>(s->wait_timeout_s * 1e8);
+      HIP_TRY(s->px_map.upload(std::vector<saa::PeerMap>(1, s->peer)));
+    }
+    return SAA_OK;
+  }
+  return fail(SAA_E_ARG, "saa_set_option: unknown option '" + key + "' (synced_graph, wait_timeout_s)");
 }
 
 int saa_set_resident_kernel(saa_solver *s, int32_t enable) {

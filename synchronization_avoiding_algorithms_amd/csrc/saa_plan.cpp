@@ -773,7 +773,7 @@ bool build_once(int32_t n_nodes, int32_t n_elems, const double *xyz, const int32
   // coordinates in units of the mesh size (cube root of six mean element volumes), rounded: AxisOrder
   std::vector<int32_t> cell;
   {
-    const char *snap_env = getenv("SAA_PLAN_SNAP_CUTS");
+    const char *snap_env = diag_env("SAA_PLAN_SNAP_CUTS");
     if (!(snap_env && snap_env[0] == '0') && n_elems > 0 && nb > 1) {
       double vol = 0.0, lo[3] = {1e300, 1e300, 1e300};
       for (int32_t e = 0; e < n_elems; ++e) {
@@ -810,7 +810,7 @@ bool build_once(int32_t n_nodes, int32_t n_elems, const double *xyz, const int32
   // a node weighs the elements around it, then the weights of every block are rescaled by its measured
   // copies / mean and the bisection is repeated (a few rounds; it only moves the cuts).
   std::vector<int64_t> weight;
-  const char *wenv = getenv("SAA_PLAN_WEIGHTED");
+  const char *wenv = diag_env("SAA_PLAN_WEIGHTED");
   if (nb > 1 && !(wenv && wenv[0] == '0')) {
     weight.assign(n_nodes, 1024);
     for (int64_t i = 0; i < 4 * static_cast<int64_t>(n_elems); ++i) weight[tets[i]] += 1024;
@@ -860,7 +860,7 @@ bool build_once(int32_t n_nodes, int32_t n_elems, const double *xyz, const int32
     // re-weighted bisection leaves the copies within +-2 % of their mean, a handful of blocks a few items over the chunk
     // count the mean fits.  Those hand nodes to the sibling leaf of their last bisection - the cut between the two moves,
     // a strip of the plane it runs through changes sides - as long as the sibling stays inside the budget itself.
-    const char *rep_env = getenv("SAA_PLAN_CHUNK_REPAIR");
+    const char *rep_env = diag_env("SAA_PLAN_CHUNK_REPAIR");
     const int32_t nblk = static_cast<int32_t>(block_start.size());
     if (!(rep_env && rep_env[0] == '0') && nblk <= 256 && nblk >= 2 && (nblk & (nblk - 1)) == 0) {
       auto leaf_end = [&](int32_t b) { return b + 1 < nblk ? block_start[b + 1] : n_nodes; };
@@ -983,7 +983,7 @@ bool build_once(int32_t n_nodes, int32_t n_elems, const double *xyz, const int32
           copies[b] = cl;
           copies[b + 1] = cr;
           ok ? ++repaired : ++failed;
-          if (getenv("SAA_PLAN_DEBUG"))
+          if (diag_env("SAA_PLAN_DEBUG"))
             fprintf(stderr, "plan:   pair %d/%d: %s, cut moved by %d nodes, copies now %d / %d (last trial %d / %d)\n", b, b + 1,
                     ok ? "repaired" : "not repaired", std::abs(k - k0), copies[b], copies[b + 1], cl, cr);
           // the two leaves in their block-local order again
@@ -1043,7 +1043,7 @@ bool build_once(int32_t n_nodes, int32_t n_elems, const double *xyz, const int32
             bool over = false;
             for (int j = 0; j < 4; ++j) over |= copies[b + j] > budget;
             if (!over) continue;
-            if (getenv("SAA_PLAN_DEBUG"))
+            if (diag_env("SAA_PLAN_DEBUG"))
               fprintf(stderr, "plan:   blocks %d..%d before: %d %d %d %d\n", b, b + 3, copies[b], copies[b + 1], copies[b + 2], copies[b + 3]);
             const int32_t s0 = block_start[b], s4 = leaf_end(b + 3), m0 = block_start[b + 2] - s0;
             const int32_t heavy_left = (copies[b] + copies[b + 1] >= copies[b + 2] + copies[b + 3]) ? 1 : 0;
@@ -1122,12 +1122,12 @@ bool build_once(int32_t n_nodes, int32_t n_elems, const double *xyz, const int32
                 for (int32_t i = (j == 0 ? s0 : block_start[b + j]); i < (j == 3 ? s4 : block_start[b + j + 1]); ++i)
                   owner[plan.new_to_old[i]] = b + j;
             }
-            if (getenv("SAA_PLAN_DEBUG"))
+            if (diag_env("SAA_PLAN_DEBUG"))
               fprintf(stderr, "plan:   blocks %d..%d: %s one level up (last trial %d %d %d %d)\n", b, b + 3, ok ? "repaired" : "not repaired",
                       c4[0], c4[1], c4[2], c4[3]);
           }
         }
-        if (getenv("SAA_PLAN_DEBUG"))
+        if (diag_env("SAA_PLAN_DEBUG"))
           fprintf(stderr, "plan: chunk repair: budget %d copies per block (%d second-phase chunks), %d pairs repaired, %d not, %d groups of "
                           "four one level up\n", budget, chunks, repaired, failed, repaired4);
       }
@@ -1223,22 +1223,22 @@ bool build_once(int32_t n_nodes, int32_t n_elems, const double *xyz, const int32
   std::vector<int32_t> n_interior(n_blocks, 0), n_items(n_blocks, 0), n_paired(n_blocks, 0);
   // Idle-lane padding is OFF by default: measured on MI355X (1M tets) 14.6 us/step without, 15.4 / 16.9 /
   // 17.7 us with 10 / 30 / 50 % padding - the extra sweeps cost more than the bank clashes they remove.
-  const char *pad_env = getenv("SAA_PLAN_PAD");
+  const char *pad_env = diag_env("SAA_PLAN_PAD");
   const double pad = pad_env ? atof(pad_env) : 0.0;
   const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
   const unsigned n_thr = static_cast<unsigned>(std::min<int64_t>(hw, std::max<int32_t>(1, n_blocks / 8)));
   std::vector<PackStats> stats(n_thr);
   std::vector<std::vector<uint16_t>> block_perm(n_blocks);  // non-empty: old -> new local index of the block's owned nodes
   std::vector<std::vector<uint16_t>> block_halo_perm(n_blocks);  // non-empty: old -> new position in the block's halo list
-  const char *shp_env = getenv("SAA_PLAN_SHAPE_PAIRS");
+  const char *shp_env = diag_env("SAA_PLAN_SHAPE_PAIRS");
   const bool shape_pairs = !(shp_env && shp_env[0] == '0');
-  const char *force_env = getenv("SAA_PLAN_FORCE_TRIALS");  // (experiments: try the other numberings on every block)
+  const char *force_env = diag_env("SAA_PLAN_FORCE_TRIALS");  // (experiments: try the other numberings on every block)
   const bool force_trials = force_env && force_env[0] == '1';
-  const char *lat_env = getenv("SAA_PLAN_LATTICE_ORDERS");
+  const char *lat_env = diag_env("SAA_PLAN_LATTICE_ORDERS");
   const bool lattice_orders = !(lat_env && lat_env[0] == '0');
   std::atomic<int32_t> renumbered{0};
   std::atomic<int32_t> q_hist[12] = {};
-  const char *alt_env = getenv("SAA_PLAN_FIXED_AXES");
+  const char *alt_env = diag_env("SAA_PLAN_FIXED_AXES");
   const bool alt_axes = !(alt_env && alt_env[0] == '1');
   // One block per CU and 1024-thread workgroups (api: pick_threads): the resident kernel runs a block's first 1024
   // interior items before the halo arrives and EVERYTHING else as one second list - further interior items together with
@@ -1247,7 +1247,7 @@ bool build_once(int32_t n_nodes, int32_t n_elems, const double *xyz, const int32
   // four SIMDs gets 11 chunks instead of 10, and since every block waits for its neighbours those blocks pace all.
   int64_t max_copies = 0;
   for (int32_t b = 0; b < n_blocks; ++b) max_copies = std::max<int64_t>(max_copies, off[b + 1] - off[b]);
-  const char *cap_env = getenv("SAA_PLAN_FIRST_ROUND_CAP");
+  const char *cap_env = diag_env("SAA_PLAN_FIRST_ROUND_CAP");
   const bool cap_on = !(cap_env && cap_env[0] == '0');
   const int32_t first_round_cap = (cap_on && second_list_pays && n_blocks <= 256 && max_copies >= 4096) ? 1024 : INT32_MAX;
   std::atomic<int32_t> next{0};
@@ -1372,7 +1372,7 @@ bool build_once(int32_t n_nodes, int32_t n_elems, const double *xyz, const int32
       if (!best.pio.empty()) block_perm[b] = best.pio;
       if (!best.pih.empty()) block_halo_perm[b] = best.pih;
       renumbered += best_q >= 6;
-      if (getenv("SAA_PLAN_DEBUG")) ++q_hist[best_q];
+      if (diag_env("SAA_PLAN_DEBUG")) ++q_hist[best_q];
       part_a.swap(best.pa);
       part_b.swap(best.pb);
       const PackStats st_in = best.si, st_bd = best.sb;
@@ -1411,7 +1411,7 @@ bool build_once(int32_t n_nodes, int32_t n_elems, const double *xyz, const int32
     for (size_t h = 0; h < ph.size(); ++h) moved[ph[h]] = seg[h];
     std::copy(moved.begin(), moved.end(), seg);
   }
-  if (getenv("SAA_PLAN_DEBUG")) {
+  if (diag_env("SAA_PLAN_DEBUG")) {
     fprintf(stderr, "plan: %d of %d blocks took a pseudo-lattice numbering; blocks per numbering 0..11:", renumbered.load(), n_blocks);
     for (auto &h : q_hist) fprintf(stderr, " %d", h.load());
     fprintf(stderr, "\n");
@@ -1420,7 +1420,8 @@ bool build_once(int32_t n_nodes, int32_t n_elems, const double *xyz, const int32
   {
     int32_t n_changed = 0;
     for (int32_t b = 0; b < n_blocks; ++b) n_changed += !block_perm[b].empty();
-    if (getenv("SAA_PLAN_DEBUG")) fprintf(stderr, "plan: %d of %d blocks took another axis order\n", n_changed, n_blocks);
+    if (diag_env("SAA_PLAN_DEBUG")) fprintf(stderr, "plan: %d of %d blocks took another axis order\n", n_changed, n_blocks);
+    plan.n_renumbered = n_changed;
     if (n_changed > 0) {
       std::vector<int32_t> moved(plan.new_to_old);
       for (int32_t b = 0; b < n_blocks; ++b) {
@@ -1472,7 +1473,7 @@ bool build_once(int32_t n_nodes, int32_t n_elems, const double *xyz, const int32
   plan.lds_conflict_factor = tot.read_cnt ? tot.read_mult / tot.read_cnt : 1.0;
   plan.lds_atomic_conflict_factor = tot.atomic_cnt ? tot.atomic_mult / tot.atomic_cnt : 1.0;
   plan.n_by_construction = tot.by_construction;
-  if (getenv("SAA_PLAN_DEBUG")) {
+  if (diag_env("SAA_PLAN_DEBUG")) {
     // distribution of the per-block work (items) and of its interior / boundary split
     int32_t mn = INT32_MAX, mx = 0, mxi = 0, mxb = 0;
     double sum = 0;
@@ -1510,7 +1511,7 @@ bool build_once(int32_t n_nodes, int32_t n_elems, const double *xyz, const int32
       for (int j = 0; j < 8; ++j)
         if (hist[i][j]) fprintf(stderr, "plan:   %d blocks with %d interior + %d boundary rounds of 1024 items\n", hist[i][j], i, j);
   }
-  if (getenv("SAA_PLAN_DEBUG"))
+  if (diag_env("SAA_PLAN_DEBUG"))
     fprintf(stderr,
             "plan: %lld element copies in %lld items (%lld pairs, %lld in clash-free halves by construction); read conflict "
             "factor %.3f, atomic %.3f (%u threads)\n",
@@ -1552,7 +1553,7 @@ bool build_plan(int32_t n_nodes, int32_t n_elems, const double *xyz, const int32
       if (overflow > 0 && overflow <= 24 && !retried) {
         retried = true;
         margin += overflow + 2;
-        if (getenv("SAA_PLAN_DEBUG")) fprintf(stderr, "plan: fullest block %d items over its chunks: again with a margin of %d\n", overflow, margin);
+        if (diag_env("SAA_PLAN_DEBUG")) fprintf(stderr, "plan: fullest block %d items over its chunks: again with a margin of %d\n", overflow, margin);
         continue;
       }
       return true;

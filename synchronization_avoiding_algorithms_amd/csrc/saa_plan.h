@@ -8,10 +8,20 @@
 // summation order is fixed by the plan.
 #pragma once
 #include <cstdint>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
 namespace saa {
+
+// Switches of measured-and-rejected plan / launch variants (SAA_PLAN_*, SAA_PERSIST_CHUNK, SAA_SHARED_NODE_WORK,
+// SAA_RESIDENT_TRUST_GRID, SAA_NO_PERSISTENT) exist only in the diagnostic build (-DSAA_DIAGNOSTICS, tools/); the product
+// library reads no environment variable.
+#ifdef SAA_DIAGNOSTICS
+inline const char *diag_env(const char *name) { return std::getenv(name); }
+#else
+inline const char *diag_env(const char *) { return nullptr; }
+#endif
 
 struct BlockDesc {
   int32_t node_start;  // first owned node (internal numbering)
@@ -56,6 +66,7 @@ struct Plan {
   double lds_conflict_factor = 1.0; // mean over (ds_read_b128 lane group, vertex slot) of the worst bank multiplicity
   double lds_atomic_conflict_factor = 1.0;  // the same for the ds_add_f64 of a half-wave (owned vertices only)
   int64_t n_by_construction = 0;    // item slots in half-waves that are clash-free by construction (pattern classes)
+  int32_t n_renumbered = 0;         // blocks whose nodes took another order than the plan's (axis order / pseudo-lattice)
   int32_t max_owned = 0, max_local = 0;
   int64_t n_elem_copies = 0, n_halo_total = 0;
 };

@@ -38,7 +38,8 @@ class PartitionedSolver:
     def __init__(self, points, cells, facets_or_dirichlet_nodes, epart, rank, world,
                  E=1e6, nu=0.3, rho=1.0, fz=0.5, alpha=0.5, gamma=0.9, device=0, process_group=None,
                  tensor_device=None, solver_factory: Optional[Callable] = None, block_nodes=0, threads=0,
-                 native_exchange=True, exchange="auto", setup_fields: Optional[Callable] = None):
+                 native_exchange=True, exchange="auto", setup_fields: Optional[Callable] = None,
+                 wait_timeout_s: Optional[float] = None, resident_on_shared_device=False):
         import torch
 
         self.rank, self.world = int(rank), int(world)
@@ -85,6 +86,11 @@ class PartitionedSolver:
         self.input_size = 3 * len(lay.shared_nodes)          # Online_predictor.py:126
         self.steps_done = 0
         self.device_ordinal = int(device)
+        # ranks sharing one GPU (rehearsals, the one-GPU test box) keep one launch per step unless told otherwise: a
+        # resident kernel waiting for another process' kernel only advances by time-slicing
+        self._resident_on_shared_device = bool(resident_on_shared_device)
+        if wait_timeout_s is not None and hasattr(self.solver, "set_option"):
+            self.solver.set_option("wait_timeout_s", wait_timeout_s)  # bound of the in-kernel waits for other ranks
         # how the shared-node forces travel in synchronised steps (all ranks agree on one of them):
         #   "peer"  direct xGMI peer stores + rank-ordered sums (saa_step_peer), no collective
         #   "rccl"  ncclAllReduce issued from C++ (saa_step_synced)
@@ -123,12 +129,8 @@ class PartitionedSolver:
         info = (ok, handle, self.device_ordinal, slots, order, self._physical_device_id())
         box = [None] * self.world
         dist.all_gather_object(box, info, group=self.group)
-        import os
-
         if (len({b[5] for b in box}) < self.world and hasattr(self.solver, "set_resident_kernel")
-                and os.environ.get("SAA_FORCE_RESIDENT") != "1"):  # (the override is for tests of that very path)
-            # ranks sharing one GPU (rehearsals, the one-GPU test box): a resident kernel waiting for another
-            # process' kernel only advances by time-slicing - keep one launch per step
+                and not self._resident_on_shared_device):
             self.solver.set_resident_kernel(False)
         if min(b[0] for b in box) == 0:
             return False

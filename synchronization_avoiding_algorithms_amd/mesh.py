@@ -10,6 +10,7 @@ module provides
 * :func:`structured_beam` – the deterministic synthetic ``25n x n x n`` cantilever of
   ``SURVEY.md`` §8(d): cubes split into 6 positively oriented Kuhn tetrahedra over the
   box of ``Mesh_info/beam_US.geo:2-16``,
+* :func:`delaunay_beam` – the same box meshed without any lattice (Delaunay tetrahedra of random points),
 * :func:`slab_partition` / :func:`rcb_partition` – element partition vectors playing the
   role of ``part_mesh_kway``'s ``epart`` (one part per GPU).
 
@@ -139,6 +140,74 @@ def structured_beam(n: int, length: float = 25.0, width: float = 1.0, height: fl
         np.stack([nid(z0, fj, fk), nid(z0, fj + 1, fk + 1), nid(z0, fj, fk + 1)], axis=1),
     ])
     return Mesh(pts, {"tetra": tets, "triangle": tri})
+
+
+def delaunay_beam(n: int, length: float = 25.0, width: float = 1.0, height: float = 1.0, seed: int = 0,
+                  sliver: float = 0.02, density: float = 1.1) -> Mesh:
+    """An UNSTRUCTURED mesh of the box of ``Mesh_info/beam_US.geo:2-16`` at the scale of :func:`structured_beam` ``(n)``:
+    Delaunay tetrahedra (Qhull through SciPy) of random points - no lattice anywhere in the connectivity (node valences
+    1...45, ~5 tets per node), the class of mesh Gmsh writes for the reference (``Mesh_info/beam_coarse.vtk``).
+
+    Points: a hard-core random process in the interior (uniform candidates, a candidate is dropped when an earlier one
+    lies within 0.55 of the mean spacing ``1/n`` - Gmsh's nodes keep their distance too), ``density`` x the structured
+    beam's node count in all; on the clamp plane ``x = 0`` the exact grid of spacing ``1/n`` (planar, so that
+    ``Data_prepare.py:127-136`` finds its facets); on the other five faces the grid points moved by up to 0.3/n inside the
+    face and lifted outward by <= 0.03/n along a smooth bulge (a hull in general position: with coplanar face points Qhull
+    needs 8x as long; the shape changes by 0.2 % of the width).  Tets are oriented positively (the reference keeps ``detJ``
+    signed, ``Mat_construction.py:93``); slivers - volume below ``sliver`` x the cube of the longest edge, whose
+    ``1/detJ`` makes any two fp64 evaluations of ``K_e`` disagree and which no explicit scheme with an edge-based time
+    step survives - are dropped (10 % of the tets, 4 % of the volume: small voids).  Deterministic for a given ``seed``.
+    n = 19: ~209 000 nodes, ~1.03 M tets, 15 s."""
+    from scipy.spatial import Delaunay, cKDTree
+
+    if n < 2:
+        raise ValueError("n must be >= 2")
+    dims = np.array([length, width, height], dtype=np.float64)
+    nx, ny, nz = int(round(length / width)) * n, n, n
+    h = width / n
+    X, Y, Z = np.meshgrid(np.linspace(0.0, length, nx + 1), np.linspace(0.0, width, ny + 1),
+                          np.linspace(0.0, height, nz + 1), indexing="ij")
+    on_face = np.zeros(X.shape, dtype=bool)
+    on_face[[0, -1], :, :] = on_face[:, [0, -1], :] = on_face[:, :, [0, -1]] = True
+    grid = np.stack([X[on_face], Y[on_face], Z[on_face]], axis=1)
+    rng = np.random.default_rng(seed)
+    wall = grid[:, 0] < 1e-12
+    faces = grid.copy()
+    for ax in range(3):  # inside the face
+        free = (grid[:, ax] > 1e-9) & (grid[:, ax] < dims[ax] - 1e-9) & ~wall
+        faces[free, ax] += rng.uniform(-0.3 * h, 0.3 * h, size=int(free.sum()))
+    u = faces / dims
+    for ax, (a, b) in enumerate(((1, 2), (0, 2), (0, 1))):  # outward, by a strictly concave function of the other two
+        bump = 0.02 * h * (2.0 * (u[:, a] * (1.0 - u[:, a]) + u[:, b] * (1.0 - u[:, b])) + 0.05)
+        lo = (grid[:, ax] < 1e-9) & ~wall
+        hi = (grid[:, ax] > dims[ax] - 1e-9) & ~wall
+        if ax > 0:
+            faces[lo, ax] -= bump[lo]
+        faces[hi, ax] += bump[hi]
+    want = int(density * X.size) - len(faces)
+    cand = rng.uniform(0.5 * h, dims - 0.5 * h, size=(int(2.4 * want), 3))
+    close = cKDTree(cand).query_pairs(0.55 * h, output_type="ndarray")  # pairs (i < j)
+    drop = np.zeros(len(cand), dtype=bool)
+    drop[close[:, 1]] = True  # a candidate with an earlier one too close
+    pts = np.concatenate([faces, cand[~drop][:want]])
+    tri = Delaunay(pts)
+    tets = tri.simplices.astype(np.int64)
+    p = pts[tets]
+    e = p[:, 1:] - p[:, :1]
+    vol = np.einsum("ij,ij->i", e[:, 0], np.cross(e[:, 1], e[:, 2])) / 6.0
+    neg = vol < 0
+    tets[neg] = tets[neg][:, [0, 1, 3, 2]]
+    longest = np.zeros(len(tets))
+    for a in range(4):
+        for b in range(a + 1, 4):
+            longest = np.maximum(longest, np.linalg.norm(p[:, a] - p[:, b], axis=1))
+    tets = tets[np.abs(vol) > sliver * longest ** 3]
+    used = np.unique(tets)
+    remap = np.full(len(pts), -1, dtype=np.int64)
+    remap[used] = np.arange(len(used))
+    hull = tri.convex_hull
+    hull = hull[np.all(pts[hull, 0] < 1e-12, axis=1) & np.all(remap[hull] >= 0, axis=1)]
+    return Mesh(pts[used], {"tetra": remap[tets], "triangle": remap[hull]})
 
 
 def clamp_nodes(mesh: Mesh, tol: float = 1e-9) -> np.ndarray:

@@ -222,21 +222,22 @@ class DevicePredictor:
     """Callable for :func:`distributed.run_hybrid`: keeps model and scaling on the solver's device.
 
     On a GPU the window's table comes from :class:`NativePredictor` (the library's own kernels; four launches).
-    ``SAA_PREDICT_NATIVE=0`` selects the PyTorch-ROCm path instead (MIOpen / rocBLAS): one call is ~600 launches of
+    ``backend="torch"`` selects the PyTorch-ROCm path instead (MIOpen / rocBLAS): one call is ~600 launches of
     microsecond kernels (7 ms from Python for 1.5 ms of GPU work, against ~33 ms of time stepping per window), so it is
     captured as a HIP graph after ``warmup`` eager calls and replayed: the window position ``n`` lives in a device scalar,
     the history tensor and the output table are static (``run_hybrid`` allocates the history once and consumes the table
     before the next call).  On the CPU (the drop-in's ``device='cpu'``) the call is the eager batched PyTorch one."""
 
-    def __init__(self, model, n_past, n_future, filter_size, scale_max, scale_min, warmup=2):
-        import os
-
+    def __init__(self, model, n_past, n_future, filter_size, scale_max, scale_min, warmup=2, backend="native",
+                 graph=True):
+        if backend not in ("native", "torch"):
+            raise ValueError("backend must be 'native' (the library's predictor kernels) or 'torch' (PyTorch-ROCm)")
         self.model = model.eval()
         self.n_p, self.n_f, self.n_s = n_past, n_future, filter_size
         self.scale_max, self.scale_min = float(scale_max), float(scale_min)
         self._graph, self._key, self._calls, self._warmup = None, None, 0, warmup
-        self._use_graph = os.environ.get("SAA_PREDICT_GRAPH", "1") != "0"
-        self._use_native = os.environ.get("SAA_PREDICT_NATIVE", "1") != "0" and filter_size >= 2
+        self._use_graph = bool(graph)
+        self._use_native = backend == "native" and filter_size >= 2
         self._native, self._native_table = None, None
 
     def _eager(self, n, hist):

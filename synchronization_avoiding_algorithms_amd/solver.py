@@ -126,6 +126,11 @@ class HipExplicitSolver:
     def set_resident_kernel(self, enable: bool):
         _lib.check(self._lib.saa_set_resident_kernel(self._h, 1 if enable else 0))
 
+    def set_option(self, name: str, value: float):
+        """Run-time options by name (``saa_set_option``): ``synced_graph`` (1/0: graph replays / eager launches in
+        :meth:`step_synced`), ``wait_timeout_s`` (bound of every in-kernel wait for another workgroup or rank)."""
+        _lib.check(self._lib.saa_set_option(self._h, name.encode(), float(value)))
+
     def set_deterministic(self, enable: bool):
         """Atomic-free two-kernel steps with a fixed summation order: bit-identical results from run to run
         (``saa_set_deterministic``; a verification mode, several times slower)."""

@@ -52,8 +52,9 @@ def _decode(model, X, n_future):
     return torch.stack(outs, dim=1)
 
 
-_FOLDED = __import__("os").environ.get("SAA_TRAIN_FOLDED", "1") != "0"
-_FUSED_CELL = __import__("os").environ.get("SAA_TRAIN_FUSED_CELL", "1") != "0"
+#: GPU formulation of the training pass (tests flip them to compare with the literal form; the CPU path is always literal)
+_FOLDED = True          # decoder feedback folded into the recurrent matrix (_decode_folded)
+_FUSED_CELL = True      # pointwise part of an LSTM step as one library kernel (_FusedCell)
 
 
 class _FusedCell(torch.autograd.Function):
@@ -93,7 +94,7 @@ class _FusedCell(torch.autograd.Function):
         return dgates, dc_prev
 
 
-_FUSED_RECURRENCE = __import__("os").environ.get("SAA_TRAIN_FUSED_RECURRENCE", "1") != "0"
+_FUSED_RECURRENCE = True  # whole recurrences as single launches (_Recurrence)
 
 
 class _Recurrence(torch.autograd.Function):
@@ -188,8 +189,8 @@ def _cell(gates, c):
 
 
 def _decode_folded(model, X, n_future):
-    """The same function of the same parameters with the decoder's feedback folded (GPU only; ``SAA_TRAIN_FOLDED=0``
-    keeps the literal form, which the CPU path always uses): from its second step on the decoder's input is
+    """The same function of the same parameters with the decoder's feedback folded (GPU only; the CPU path always
+    keeps the literal form): from its second step on the decoder's input is
     ``fc(h) = h W_fc^T + b_fc``, so ``gates = fc(h) W_ih^T + h W_hh^T + b = h (W_ih W_fc + W_hh)^T + (W_ih b_fc + b)``.
     The folded matrix is formed once per pass (a 4D x I by I x D product) and every step is a D -> 4D product instead of
     an I -> 4D one plus an ``nn.LSTM`` call; the outputs of all steps come from one product at the end.  Autograd
@@ -413,7 +414,7 @@ def windows_from_history(hist, filter_size, n_past, n_future, cut_off=1.0):
 
 
 def fit_windows(X, Y, hidden_size=50, batch_size=10, learning_rate=5e-4, decay=0.998, lr_min=5e-7, T_portion=0.75,
-                num_epochs=None, max_seconds=None, generator=None, verbose=False, rank=0, log=None):
+                num_epochs=None, max_seconds=None, generator=None, verbose=False, rank=0, log=None, graph=None):
     """The training loop of ``Model_training.py:60-139`` on already scaled windows ``X (groups, n_past, in)``,
     ``Y (groups, n_future, in)``: Adam, learning rate ``decay**epoch``, random ``T_portion`` training split, shuffled
     mini-batches, validation on the rest; on a GPU the optimiser step is replayed as a HIP graph.  Stops after
@@ -426,10 +427,10 @@ def fit_windows(X, Y, hidden_size=50, batch_size=10, learning_rate=5e-4, decay=0
     n_future = Y.shape[1]
     model = LSTM_encoder_decoder(X.shape[2], hidden_size, 2, True, 0.0, 0.0).to(device)
     criterion = nn.MSELoss()
-    use_graph = device.type == "cuda" and os.environ.get("SAA_TRAIN_GRAPH", "1") != "0"
+    use_graph = device.type == "cuda" and (graph is None or bool(graph))
     if use_graph:  # capturable Adam with a tensor learning rate: the scheduler's updates reach the graph replays
         optimizer = torch.optim.Adam(model.parameters(), lr=torch.tensor(learning_rate, device=device), capturable=True,
-                                     fused=os.environ.get("SAA_TRAIN_FUSED_ADAM", "1") != "0")  # one kernel, one pass over the parameters
+                                     fused=True)  # one kernel, one pass over the parameters
     else:
         optimizer = torch.optim.Adam(model.parameters(), lr=learning_rate)
     scheduler = torch.optim.lr_scheduler.LambdaLR(optimizer, lr_lambda=lambda epoch: decay ** epoch)
@@ -483,8 +484,9 @@ def train_on_history(hist, filter_size, n_past, n_future, cut_off=1.0, seed=None
 
 def train_rank_model(out_dir=".", rank=0, device=None, batch_size=10, learning_rate=5e-4, hidden_size=50,
                      filter_size=150, cut_off=0.5, lr_min=5e-7, decay=0.998, T_portion=0.75, n_future=20, n_past=20,
-                     num_epochs=None, seed=None, verbose=False):
-    """``Model_training.py:17-181`` for one rank; returns ``(model_path, train_loss, validation_loss)``."""
+                     num_epochs=None, seed=None, verbose=False, graph=None):
+    """``Model_training.py:17-181`` for one rank; returns ``(model_path, train_loss, validation_loss)``.  ``graph``: on a
+    GPU, replay the optimiser step as a HIP graph (default) or launch it eagerly (False)."""
     from .drivers import PATHS
 
     device = torch.device(device if device is not None else ("cuda" if torch.cuda.is_available() else "cpu"))
@@ -502,7 +504,7 @@ def train_rank_model(out_dir=".", rank=0, device=None, batch_size=10, learning_r
     X, Y = windowed_dataset(traj, filter_size, n_past, n_future, cut_off, device)
     X, Y, _, _ = scale_to_zero_one(X, Y)
     model, train_loss, test_loss = fit_windows(X, Y, hidden_size, batch_size, learning_rate, decay, lr_min, T_portion,
-                                               num_epochs, None, gen, verbose, rank)
+                                               num_epochs, None, gen, verbose, rank, graph=graph)
     path = os.path.join(out_dir, PATHS["model"].format(r=rank, nB=batch_size, nH=hidden_size, lr=learning_rate,
                                                        ns=filter_size))
     os.makedirs(os.path.dirname(path), exist_ok=True)

@@ -175,8 +175,6 @@ def _three_rank_worker(rank, world, port, out_dir, use_gpu, exchange="auto", for
     sys.path.insert(0, REPO)
     sys.path.insert(0, os.path.join(REPO, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-    if force_resident:  # ranks share the test GPU: keep the resident kernel on anyway (that is what is under test)
-        os.environ.update(SAA_FORCE_RESIDENT="1", SAA_PEER_TIMEOUT_S="20")
     if use_gpu:
         torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -187,6 +185,8 @@ def _three_rank_worker(rank, world, port, out_dir, use_gpu, exchange="auto", for
     mesh = structured_beam(3, length=4.0)
     epart = _t_partition(mesh)
     kw = {} if use_gpu else dict(tensor_device=torch.device("cpu"), solver_factory=lambda **k: CpuSolverDouble(**k), setup_fields=host_setup_fields)
+    if force_resident:  # ranks share the test GPU: keep the resident kernel on anyway (that is what is under test)
+        kw.update(wait_timeout_s=20, resident_on_shared_device=True)
     part = PartitionedSolver(mesh.points, mesh.tets, mesh.triangles, epart, rank, world, exchange=exchange, **kw)
     assert part.exchange == (exchange if use_gpu else "torch"), part.exchange
     part.step_synced(150)

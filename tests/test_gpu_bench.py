@@ -31,7 +31,7 @@ def _run(*flags, timeout=900, extra_env=None, expect_rc=0):
 def test_two_ranks_launch_themselves_and_print_one_line():
     """N = 2 on the one-GPU box: both ranks share cuda:0, gloo process group (what --same-device is for)."""
     out = _run("--gpus", "2", "--same-device", "--backend", "gloo", "--refine", "4", "--steps", "40", "--warmup", "10",
-               "--sa-train-epochs", str(SA_EPOCHS), "--sa-truth-steps", "24000")
+               "--sa-train-epochs", str(SA_EPOCHS), "--sa-truth-steps", "24000", "--min-timed-ms", "50")
     assert out["n_gpus"] == 2 and out["steps"] == 40 and out["warmup"] == 10 and out["timed_calls"] >= 1
     assert out["metric"] == "element_updates_per_s" and out["value"] > 0 and out["scaling"] == "weak"
     assert "2 x-slab" in out["config"]["workload"]
@@ -59,9 +59,9 @@ def test_line_survives_a_hung_preflight_and_a_stalled_rccl_leg():
 
     t0 = time.time()
     out = _run("--gpus", "2", "--same-device", "--backend", "gloo", "--refine", "4", "--steps", "40", "--warmup", "10",
-               "--sa-train-epochs", "3", "--sa-truth-steps", "12000", "--budget-s", "240", expect_rc=3,
-               extra_env={"SAA_BENCH_FORCE_PREFLIGHT": "1", "SAA_BENCH_TEST_PREFLIGHT": "hang",
-                          "SAA_BENCH_FORCE_RCCL_LEG": "1", "SAA_BENCH_TEST_STALL_RCCL": "1"})
+               "--sa-train-epochs", "3", "--sa-truth-steps", "12000", "--budget-s", "240", "--force-preflight",
+               "--force-rccl-leg", "--min-timed-ms", "50", expect_rc=3,
+               extra_env={"SAA_BENCH_HOOKS": "tests.bench_hooks", "SAA_BENCH_HOOK_PLAN": "preflight=hang,rccl_leg=hang"})
     wall = time.time() - t0
     assert wall < 240 + 20, wall
     assert out["value"] > 0 and out["config"]["peer_preflight_rank0"] is False
@@ -76,9 +76,24 @@ def test_line_survives_a_hung_preflight_and_a_stalled_rccl_leg():
 def test_headline_at_the_drivers_flags_is_warm():
     """The driver's own command (BENCH_r01.json: --steps 20 --warmup 5).  Round 1 timed a cold first cooperative
     launch there (33x below the kernel's rate); the timed call must run warm and agree with the kernel-level figure."""
-    out = _run("--gpus", "1", "--steps", "20", "--warmup", "5", "--no-cpu-baseline")
+    out = _run("--gpus", "1", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--min-timed-ms", "200",
+               "--legs", "roofline,per_gpu_of_8,cache_exceeding,predictor", "--big-refine", "10")
     roof = out["roofline"]
     assert roof["launches_timed"] >= 10 and 0.3 < roof["frac"] < 1.5
+    assert roof["timed_region_ms"] >= 900 and roof["short_region"]["launches"] == 12   # sustained figure beside the short one
+    # counters from committed profiles are printed only for the plan that was profiled - and then name the limiter
+    if roof["traffic"] is not None:
+        assert roof["hbm_measured"]["traffic_over_algorithmic"] < 1.0 and roof["bound"].startswith("on-chip"), roof["bound"]
+    # the per-GPU workload of configs[3] / [4] (here on a small beam) through every route a step can take
+    per = out["per_gpu_of_8"]
+    assert out["legs"]["per_gpu_of_8"] == "done", (out["legs"], per)
+    assert set(per["routes"]) == {"plain", "peer_loopback", "rccl_eager", "rccl_graph", "sync_avoiding"}
+    assert all(r["us_per_step"] > 0 for r in per["routes"].values()) and per["routes"]["sync_avoiding"]["state_finite"]
+    assert per["routes"]["sync_avoiding"]["windows"] >= 3 and set(per["projected_8gpu"]["element_updates_per_s"]) == \
+        {"peer_loopback", "rccl_eager", "rccl_graph", "sync_avoiding"}
+    big = out["cache_exceeding"]
+    assert out["legs"]["cache_exceeding"] == "done" and big["ms_per_step"] > 0 and 0 < big["roofline"]["frac"] < 1.5, big
+    assert out["legs"]["unstructured"].startswith("skipped")
     # the practical HBM ceiling comes from the library's own 16-byte-per-lane copy kernel (the guide: 6.29 TB/s)
     assert 5000 < roof["measured_copy_GBps"] < 8000, roof["measured_copy_GBps"]
     assert out["legs"]["roofline"] == "done" and out["legs"]["cpu_baseline"].startswith("skipped")

@@ -211,11 +211,8 @@ def test_native_rccl_exchange_single_rank(beam_coarse):
     eager.set_interface_buffer(iface2)
     eager.set_stream(torch.cuda.current_stream().cuda_stream)
     eager.comm_init(eager.comm_unique_id(), 0, 1)
-    os.environ["SAA_SYNCED_GRAPH"] = "0"
-    try:
-        eager.step_synced(400)
-    finally:
-        del os.environ["SAA_SYNCED_GRAPH"]
+    eager.set_option("synced_graph", 0)
+    eager.step_synced(400)
     plain.step(200)
     synced.step_synced(100)
     synced.step_synced(100)
@@ -311,15 +308,15 @@ def test_three_ranks_resident_kernel_with_triple_owned_nodes(tmp_path):
 
 def _resident_peer_worker(rank, world, port, out_dir):
     sys.path.insert(0, REPO)
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0",
-                      SAA_FORCE_RESIDENT="1", SAA_PEER_TIMEOUT_S="20")
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from synchronization_avoiding_algorithms_amd.distributed import PartitionedSolver
 
     g = np.load(os.path.join(GOLDEN, "beam_coarse_mesh.npz"))
     t = np.load(os.path.join(GOLDEN, "tworank_trajectory.npz"))
-    part = PartitionedSolver(g["points"], g["tetra"], g["triangle"], t["epart"], rank, world, device=0, exchange="peer")
+    part = PartitionedSolver(g["points"], g["tetra"], g["triangle"], t["epart"], rank, world, device=0, exchange="peer",
+                             wait_timeout_s=20, resident_on_shared_device=True)
     assert part.exchange == "peer" and part.solver.resident_kernel_info()["capable"]
     hist = torch.zeros((100, part.input_size), dtype=torch.float64, device="cuda")
     part.step_synced(1, hist, 0)     # one launch per step
@@ -348,15 +345,15 @@ def test_resident_kernel_with_peer_exchange_between_processes(tmp_path):
 
 def _dead_peer_worker(rank, world, port, out_dir):
     sys.path.insert(0, REPO)
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0",
-                      SAA_PEER_TIMEOUT_S="0.3")
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from synchronization_avoiding_algorithms_amd.distributed import PartitionedSolver
 
     g = np.load(os.path.join(GOLDEN, "beam_coarse_mesh.npz"))
     t = np.load(os.path.join(GOLDEN, "tworank_trajectory.npz"))
-    part = PartitionedSolver(g["points"], g["tetra"], g["triangle"], t["epart"], rank, world, device=0, exchange="peer")
+    part = PartitionedSolver(g["points"], g["tetra"], g["triangle"], t["epart"], rank, world, device=0, exchange="peer",
+                             wait_timeout_s=0.3)
     assert part.exchange == "peer"
     part.step_synced(3)
     part.get_state()

@@ -50,21 +50,20 @@ import pytest  # noqa: E402
 
 
 @pytest.mark.gpu
-def test_device_predictor_graph_replay_equals_eager_calls(monkeypatch):
-    """The PyTorch-ROCm route of DevicePredictor (SAA_PREDICT_NATIVE=0; the default on a GPU is the library's own
+def test_device_predictor_graph_replay_equals_eager_calls():
+    """The PyTorch-ROCm route of DevicePredictor (backend="torch"; the default on a GPU is the library's own
     kernels, tests/test_gpu_predictor.py) replays the per-window prediction as a HIP graph after two eager calls; the
     window position is a device scalar, so one capture serves every window."""
     import torch
 
     from synchronization_avoiding_algorithms_amd import predictor as pr
 
-    monkeypatch.setenv("SAA_PREDICT_NATIVE", "0")
     torch.manual_seed(3)
     dev = torch.device("cuda")
     n_p, n_f, n_s, insz = 4, 3, 10, 18
     model = pr.LSTM_encoder_decoder(insz, 8).to(dev).eval()
     hist = torch.randn(400, insz, dtype=torch.float64, device=dev) * 1e-3
-    p = pr.DevicePredictor(model, n_p, n_f, n_s, 2e-3, -2e-3)
+    p = pr.DevicePredictor(model, n_p, n_f, n_s, 2e-3, -2e-3, backend="torch")
     assert p.backend == "PyTorch-ROCm, HIP graph"
     with torch.no_grad():
         for n in (40, 70, 100, 133, 260, 41):
@@ -79,12 +78,11 @@ def test_device_predictor_graph_replay_equals_eager_calls(monkeypatch):
 
 
 @pytest.mark.gpu
-def test_reference_shaped_table_on_the_gpu(tmp_path, monkeypatch):
+def test_reference_shaped_table_on_the_gpu(tmp_path):
     """The fixture at the reference's real shape (24 inputs, H = 50, n_p = n_f = 20) through MIOpen / rocBLAS on the
     GPU, eager and as the replayed HIP graph of DevicePredictor's PyTorch-ROCm route (fp32: 1e-4 of the table's range)."""
-    monkeypatch.setenv("SAA_PREDICT_NATIVE", "0")
     g, model, (smax, smin) = _table_against_reference(tmp_path, "cuda", 1e-4)
-    dev = pr.DevicePredictor(model, int(g["n_p"]), int(g["n_f"]), int(g["n_s"]), smax, smin)
+    dev = pr.DevicePredictor(model, int(g["n_p"]), int(g["n_f"]), int(g["n_s"]), smax, smin, backend="torch")
     hist = torch.from_numpy(g["d_sol"]).to("cuda")
     for _ in range(4):  # eager calls, capture, replay
         table = dev(int(g["n"]), hist)

@@ -49,18 +49,18 @@ import pytest  # noqa: E402
 
 
 @pytest.mark.gpu
-def test_graph_captured_training_step_matches_eager_training(tmp_path, monkeypatch):
+def test_graph_captured_training_step_matches_eager_training(tmp_path):
     """On the GPU the optimiser step is replayed as a HIP graph (GraphedTrainStep): same seeds, same batches, same
     learning-rate schedule as eager training -> the same losses up to fp32 run-to-run noise."""
     traj = _fake_shared_trajectory(n_in=12, n_steps=4000)
     losses, paths = [], []
-    for mode in ("0", "1"):
+    for mode in (0, 1):
         out = str(tmp_path / f"graph{mode}")
         rio.save_int_list(os.path.join(out, drivers.PATHS["shared"].format(r=0)), [3, 9, 11, 17])
         rio.save_displacement(os.path.join(out, drivers.PATHS["shared_traj"].format(r=0)), traj, compress=False)
-        monkeypatch.setenv("SAA_TRAIN_GRAPH", mode)
         path, train_loss, test_loss = tr.train_rank_model(out, 0, device="cuda", hidden_size=8, filter_size=10, n_past=4,
-                                                          n_future=3, num_epochs=12, learning_rate=5e-3, seed=0)
+                                                          n_future=3, num_epochs=12, learning_rate=5e-3, seed=0,
+                                                          graph=bool(mode))
         losses.append((np.array(train_loss), np.array(test_loss)))
         paths.append(path)
     (tl0, vl0), (tl1, vl1) = losses

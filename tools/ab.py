@@ -86,7 +86,7 @@ def main():
     for case in cases:
         for r in range(rounds):
             for name, path in libs:
-                env = dict(os.environ, SAA_LIB_PATH=path)
+                env = dict(os.environ, SAA_LIB_PATH=path, SAA_ALLOW_OLD_ABI="1")
                 code = CHILD.replace("sys.argv_case", repr((case, kind))) % REPO
                 p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
                 if p.returncode != 0:

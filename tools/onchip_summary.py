@@ -29,7 +29,7 @@ def main():
     pos = [a for a in sys.argv[1:] if not a.startswith("--")]
     key, pmc_path, pmc_key = pos[0], pos[1], pos[2]
     stamps_path = pos[3] if len(pos) > 3 else None
-    steps, out_path = 1000, os.path.join(REPO, "profiles", "r03_onchip_summary.json")
+    steps, out_path = 1000, os.path.join(REPO, "profiles", "r04_onchip_summary.json")
     for a in sys.argv[1:]:
         if a.startswith("--steps-per-dispatch="):
             steps = int(a.split("=", 1)[1])

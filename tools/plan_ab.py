@@ -7,6 +7,10 @@ import subprocess
 import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _diag import diag_library_path  # noqa: E402
+
+DIAG = diag_library_path()
 world, rank = int(sys.argv[1]), int(sys.argv[2])
 rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 CHILD = r"""
@@ -22,7 +26,7 @@ print(json.dumps({'us': us, 'plan': sol.plan_stats()}))
 """ % (REPO, world, world, rank)
 for r in range(rounds):
     for cap, rep, snap in (("0", "0", "0"), ("-", "-", "-")):  # everything off / the defaults
-        env = dict(os.environ)
+        env = dict(os.environ, SAA_LIB_PATH=DIAG)  # the SAA_PLAN_* switches exist in the diagnostic build only
         if cap != "-":
             env.update(SAA_PLAN_FIRST_ROUND_CAP=cap, SAA_PLAN_CHUNK_REPAIR=rep, SAA_PLAN_SNAP_CUTS=snap)
         p = subprocess.run([sys.executable, "-c", CHILD], capture_output=True, text=True, env=env, timeout=600)

@@ -14,5 +14,5 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" \
            "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_SCA SQ_INSTS_SMEM" \
            "SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_FLOPS_FP64 SQ_INSTS_VALU SQ_WAVES"; do
   i=$((i+1))
-  timeout -k 10 280 rocprofv3 --pmc $grp -d $out/g$i -o run --output-format csv -- python3 $root/bench.py --steps 1000 --warmup 100 --no-cpu-baseline --refine $n "$@" > $out/g$i.log 2>&1 || echo "group $i failed rc=$?" >> $out/failed.txt
+  timeout -k 10 280 rocprofv3 --pmc $grp -d $out/g$i -o run --output-format csv -- python3 $root/bench.py --steps 1000 --warmup 100 --legs none --min-timed-ms 50 --refine $n "$@" > $out/g$i.log 2>&1 || echo "group $i failed rc=$?" >> $out/failed.txt
 done

@@ -6,7 +6,9 @@
 For every counter in the directory's *_counter_collection.csv files: mean value per dispatch of the kernels whose
 name contains the substring (default: "step").  With --grid G only dispatches of that grid size (threads) count,
 which separates the bench mesh from the small meshes other legs of the same command run.
-Entry name: "<key>:<COUNTER>".
+Entry name: "<key>:<COUNTER>".  With --plan-from=<log of the profiled bench run> the plan statistics and the digest of
+the kernel sources that run printed (config.plan, config.kernel_sources) are stored as "<key>:plan": bench.py hands the
+counters out only for a run with that very plan.
 """
 import csv
 import glob
@@ -58,6 +60,13 @@ def main():
         summary[f"{key}:{name}"] = {"dispatches": d["n"], "mean_per_dispatch": d["sum"] / max(d["n"], 1),
                                     "kernel": d["kernel"]}
         print(f"{key}:{name}", summary[f"{key}:{name}"])
+    for a in sys.argv[1:]:
+        if a.startswith("--plan-from="):
+            with open(a.split("=", 1)[1]) as fh:
+                lines = [ln for ln in fh if ln.lstrip().startswith("{") and '"metric"' in ln]
+            cfg = json.loads(lines[-1])["config"]
+            summary[f"{key}:plan"] = dict(cfg["plan"], kernel_sources=cfg.get("kernel_sources"))
+            print(f"{key}:plan", summary[f"{key}:plan"])
     with open(out_path, "w") as fh:
         json.dump(summary, fh, indent=1, sort_keys=True)
 

@@ -34,9 +34,7 @@ for I in sizes:
         print(f"input_size {I:5d}: 6 windows on the native kernels", flush=True)
         nat.close()
         continue
-    os.environ["SAA_PREDICT_NATIVE"] = "0"
-    graph = pr.DevicePredictor(model, n_p, n_f, n_s, smax, smin)
-    os.environ["SAA_PREDICT_NATIVE"] = "1"
+    graph = pr.DevicePredictor(model, n_p, n_f, n_s, smax, smin, backend="torch")
     with torch.no_grad():
         for _ in range(4):
             want = graph(n, hist).clone()

@@ -23,11 +23,9 @@ def rel(a, b):
 
 
 def pair(mesh, world, rank):
-    os.environ.pop("SAA_NO_PERSISTENT", None)
     res = build_rank_solver(mesh, world, rank, 0)[0]
-    os.environ["SAA_NO_PERSISTENT"] = "1"
     fus = build_rank_solver(mesh, world, rank, 0)[0]
-    os.environ.pop("SAA_NO_PERSISTENT")
+    fus.set_resident_kernel(False)
     assert res.resident_kernel_info()["capable"] and not fus.resident_kernel_info()["capable"]
     return res, fus
 

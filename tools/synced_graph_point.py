@@ -21,7 +21,7 @@ sol.set_stream(torch.cuda.current_stream().cuda_stream)
 sol.comm_init(sol.comm_unique_id(), 0, 1)
 print(f"rank 3 of 8: {len(lay.cells_local)} tets, {len(lay.shared_local)} shared nodes, buffer {iface.numel()} doubles")
 for route, env in (("eager", "0"), ("graph", "1"), ("eager", "0"), ("graph", "1")):
-    os.environ["SAA_SYNCED_GRAPH"] = env
+    sol.set_option("synced_graph", int(env))
     sol.step_synced(300)
     torch.cuda.synchronize()
     t0 = time.perf_counter()

@@ -11,6 +11,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np  # noqa: E402
 
+if any(k.startswith("SAA_PLAN_") for k in os.environ):  # those switches exist in the diagnostic build only
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from _diag import use_diag_library
+
+    use_diag_library()
+
 from bench import build_rank_solver  # noqa: E402
 from synchronization_avoiding_algorithms_amd.mesh import structured_beam  # noqa: E402
 from test_gpu_parity import _scrambled_mesh  # noqa: E402
