@@ -47,6 +47,9 @@ import numpy as np
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
+# before the first HIP call of the process (synchronization_avoiding_algorithms_amd/hip_graphs.py: captured graphs with
+# multi-block reductions replay wrongly from pre-recorded packets on this ROCm)
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
 
 E, NU, RHO, FZ, ALPHA, GAMMA = 1e6, 0.3, 1.0, 0.5, 0.5, 0.9
 HBM_PEAK = 8.0e12  # B/s, MI355X_MICROARCH.md "HBM3E peak BW"

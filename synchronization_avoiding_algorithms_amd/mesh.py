@@ -143,7 +143,7 @@ def structured_beam(n: int, length: float = 25.0, width: float = 1.0, height: fl
 
 
 def delaunay_beam(n: int, length: float = 25.0, width: float = 1.0, height: float = 1.0, seed: int = 0,
-                  sliver: float = 0.02, density: float = 1.1) -> Mesh:
+                  sliver: float = 0.02, density: float = 1.0) -> Mesh:
     """An UNSTRUCTURED mesh of the box of ``Mesh_info/beam_US.geo:2-16`` at the scale of :func:`structured_beam` ``(n)``:
     Delaunay tetrahedra (Qhull through SciPy) of random points - no lattice anywhere in the connectivity (node valences
     1...45, ~5 tets per node), the class of mesh Gmsh writes for the reference (``Mesh_info/beam_coarse.vtk``).
@@ -157,7 +157,8 @@ def delaunay_beam(n: int, length: float = 25.0, width: float = 1.0, height: floa
     signed, ``Mat_construction.py:93``); slivers - volume below ``sliver`` x the cube of the longest edge, whose
     ``1/detJ`` makes any two fp64 evaluations of ``K_e`` disagree and which no explicit scheme with an edge-based time
     step survives - are dropped (10 % of the tets, 4 % of the volume: small voids).  Deterministic for a given ``seed``.
-    n = 19: ~209 000 nodes, ~1.03 M tets, 15 s."""
+    n = 19: 190 400 nodes (the structured beam's count: one resident workgroup per CU still holds it), 1 002 482 tets,
+    10-20 s."""
     from scipy.spatial import Delaunay, cKDTree
 
     if n < 2:

@@ -282,6 +282,10 @@ class DevicePredictor:
                 self._native_table = torch.empty((self.n_s * self.n_f, hist.shape[1]), dtype=torch.float64,
                                                  device=hist.device)
             return self._native.predict(n, hist, self.scale_max, self.scale_min, self._native_table)
+        if self._use_graph and hist.is_cuda and self._graph is None:
+            from . import hip_graphs
+
+            self._use_graph = hip_graphs.replays_are_trustworthy(hist.device)  # (cached per device)
         if not (self._use_graph and hist.is_cuda):
             return self._eager(n, hist)
         if self._graph is not None and self._key != (hist.data_ptr(), tuple(hist.shape)):

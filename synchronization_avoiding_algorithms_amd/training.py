@@ -254,10 +254,10 @@ class GraphedTrainStep:
 
     def _stats(self):
         """The three running sums of ``model_train`` (``DNN_tools.py:144-155``) from the step's decoded output, computed
-        OUTSIDE the captured graph: inside it the loss value came back corrupted (negative mean squares) for stretches of
-        epochs once ~10^4 other kernels had been launched in the process, while the weights the same replays produced
-        stayed equal to eager training's to 4e-7 over 35 000 intervening launches (``tools/dbg_val.py`` history, DESIGN
-        section 7) - the value of the loss is not needed by its own backward pass, only reported."""
+        OUTSIDE the captured graph by the library's two-launch kernel (fp64 sums).  (Round 3 moved them out because the
+        loss value came back corrupted from replays; round 4 found the cause - multi-block reductions in graphs replayed
+        from pre-recorded packets, ``hip_graphs.py`` - and the graph is only used where the canary passes.  The sums stay
+        outside: one launch pair instead of a dozen tiny ATen kernels per step.)"""
         from . import _lib
 
         if not isinstance(self.criterion, nn.MSELoss) or self.out.dtype != torch.float32:
@@ -301,11 +301,9 @@ class BatchedValidation:
     per-batch mean squares of the reference's loop are segment sums of the per-window squared errors; the denominators of
     the two accuracy figures depend on the targets only and are formed once.  ~200 launches and one transfer per epoch.
 
-    (Round 2 replayed the batch loop as a HIP graph.  That graph - not the training-step graph, which was checked against
-    eager training weight by weight over 35 000 intervening launches - returns corrupted sums, negative mean squares, once
-    some ten thousand other kernels have been launched in the process since its capture: from epoch 159 of a run with the
-    graphed training step, from the first replay with eager training; reproduced in isolation by `z.add_(1)` ten
-    thousand times between two replays.  A rarely replayed captured graph is not to be trusted on this ROCm / PyTorch.)"""
+    (Round 2 replayed the batch loop as a HIP graph and got corrupted sums back - negative mean squares: its ``mse_loss``
+    / ``mean`` nodes are multi-block reductions, which replay wrongly from pre-recorded packets on this ROCm,
+    ``hip_graphs.py``.  One batched eager pass is cheaper than that graph was anyway.)"""
 
     def __init__(self, model, criterion, batches, n_future, device):
         self.model, self.n_future = model, n_future
@@ -427,7 +425,13 @@ def fit_windows(X, Y, hidden_size=50, batch_size=10, learning_rate=5e-4, decay=0
     n_future = Y.shape[1]
     model = LSTM_encoder_decoder(X.shape[2], hidden_size, 2, True, 0.0, 0.0).to(device)
     criterion = nn.MSELoss()
+    # the optimiser step as a replayed HIP graph - only where replays are proven right in this process (hip_graphs.py:
+    # the loss reduction inside the step is exactly the kind of node that replays wrongly from pre-recorded packets)
     use_graph = device.type == "cuda" and (graph is None or bool(graph))
+    if use_graph:
+        from . import hip_graphs
+
+        use_graph = hip_graphs.replays_are_trustworthy(device)
     if use_graph:  # capturable Adam with a tensor learning rate: the scheduler's updates reach the graph replays
         optimizer = torch.optim.Adam(model.parameters(), lr=torch.tensor(learning_rate, device=device), capturable=True,
                                      fused=True)  # one kernel, one pass over the parameters

@@ -342,3 +342,64 @@ def test_dropin_syn_cpus_sums_in_rank_order_where_three_ranks_meet(tmp_path):
     for r in range(world):
         got = np.load(tmp_path / f"syn{r}.npz")
         assert np.array_equal(got["out"], want[r]) and np.array_equal(got["again"], want[r]), r
+
+
+def _eight_rank_worker(rank, world, port, out_dir, steps):
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from cpu_double import CpuSolverDouble, host_setup_fields
+    from synchronization_avoiding_algorithms_amd.distributed import PartitionedSolver
+    from synchronization_avoiding_algorithms_amd.mesh import slab_partition, structured_beam
+
+    mesh = structured_beam(2)
+    part = PartitionedSolver(mesh.points, mesh.tets, mesh.triangles, slab_partition(mesh, world), rank, world,
+                             tensor_device=torch.device("cpu"), solver_factory=lambda **kw: CpuSolverDouble(**kw),
+                             setup_fields=host_setup_fields)
+    assert part.exchange == "torch"
+    hist = torch.zeros((steps, part.input_size), dtype=torch.float64)
+    part.step_synced(steps, hist, 0)
+    lay = part.layout
+    np.savez(os.path.join(out_dir, f"r{rank}.npz"), d=part.get_state()[0][:, 0], nodes=lay.nodes, elements=lay.elements,
+             shared_nodes=lay.shared_nodes, shared_slots=lay.shared_slots, dirichlet=lay.dirichlet_dofs,
+             global_shared=part.global_shared, dt=np.array([part.dt]), hist_last=hist[-1].numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_eight_ranks_on_the_eight_slab_partition_match_the_oracle(tmp_path):
+    """The shape of BASELINE.json's configs[3] - 8 ranks, one x-slab each, interior ranks with TWO neighbours - on a small
+    beam with gloo on the CPU (the driver's 8-GPU run is the first time eight real ranks meet): every rank's lists in the
+    reference's orders (Distributed_tools.py:14-62), the sorted union Global_shared (Data_prepare.py:121-124), the
+    agreed time step = min over the ranks (Data_prepare.py:147-154), and 200 synchronised steps against the oracle's
+    8-rank re-enactment of Data_prepare.py:211-240 (syn_cpus in rank order)."""
+    from oracle import fem_oracle as fo
+    from synchronization_avoiding_algorithms_amd.mesh import slab_partition, structured_beam
+
+    world, steps = 8, 200
+    port = free_port()
+    mp.spawn(_eight_rank_worker, args=(world, port, str(tmp_path), steps), nprocs=world, join=True)
+    mesh = structured_beam(2)
+    epart = slab_partition(mesh, world)
+    ranks, dt, shared, gshared = fo.setup_problem(mesh.points, mesh.tets, mesh.triangles, world, epart)
+    d0s, _, _, _ = fo.run_ground_truth(ranks, dt, steps)
+    plane = 3 * 3  # nodes of one interface plane of the 2 x 2-cube cross-section
+    assert len(gshared) == 7 * plane
+    for r in range(world):
+        got = np.load(tmp_path / f"r{r}.npz")
+        assert float(got["dt"][0]) == dt                                   # the minimum over the ranks, on every rank
+        assert np.array_equal(got["nodes"], ranks[r].nodes) and np.array_equal(got["elements"], ranks[r].ele)
+        assert np.array_equal(got["shared_nodes"], shared[r])
+        assert np.array_equal(got["global_shared"], gshared)
+        assert np.array_equal(gshared[got["shared_slots"]], shared[r])
+        assert np.array_equal(got["dirichlet"], ranks[r].dirichlet)
+        # an interior rank holds two interface planes, the end ranks one; a slab's slots are those of its planes only
+        assert len(shared[r]) == (plane if r in (0, world - 1) else 2 * plane)
+        x_of = mesh.points[shared[r], 0]
+        assert len(np.unique(np.round(x_of, 9))) == (1 if r in (0, world - 1) else 2)
+        assert rel_l2(got["d"], d0s[r][:, 0]) < 1e-12, r
+        loc = fo.node_to_dof(fo.local_index(shared[r], ranks[r].nodes))
+        assert np.array_equal(got["hist_last"], got["d"][loc])            # history row = the shared dofs after the step
+    assert max(np.abs(d[:, 0]).max() for d in d0s) > 0

@@ -1,6 +1,9 @@
-"""The topology kernels (csrc/saa_topology.hip, C ABI saa_topology_*) against the NumPy restatement of the reference's
-partition bookkeeping (fem_setup.build_rank_layout / build_layouts, themselves pinned to the reference's orderings by
-tests/test_oracle_golden.py and the two-rank fixtures): integer work - every list equal, element by element."""
+"""The topology kernels (csrc/saa_topology.hip, C ABI saa_topology_*): integer work - every list equal, element by
+element - first against the lists the REFERENCE itself produced on its own mesh (tests/golden/tworank_trajectory.npz,
+serial_setup.npz: rankwise_dist / find_shared_nodes / sort_shared / Dirichlet_rank_dist of Distributed_tools.py:14-62 and
+the clamp detection of Data_prepare.py:127-136, run by tests/golden/make_golden.py), then - on meshes and partitions the
+reference cannot run - against the NumPy restatement of that bookkeeping (fem_setup.build_rank_layout), which the CPU
+tests pin to the same goldens."""
 import numpy as np
 import pytest
 
@@ -31,6 +34,35 @@ def _check(mesh, epart, n_parts, ranks=None):
         dev2, gs2, _ = fs.device_rank_layout(mesh.tets, epart, r, n_parts, len(mesh.points), dn)
         _same(dev2, host)
         assert np.array_equal(gs2, gs_h)
+
+
+def test_device_lists_equal_the_lists_the_reference_wrote(beam_coarse):
+    """The reference's own two-rank run of beam_coarse (its element partition `epart`, then Distributed_tools.py:14-62,
+    Data_prepare.py:104-136) and its serial set-up: every list the device kernels produce equals the one the reference
+    held, entry by entry and in the reference's order."""
+    from conftest import load_golden
+
+    t, s = load_golden("tworank_trajectory.npz"), load_golden("serial_setup.npz")
+    mesh, epart = beam_coarse, t["epart"]
+    for r in range(2):
+        lay, gshared, dn = fs.device_rank_layout(mesh.tets, epart, r, 2, len(mesh.points), None, mesh.points, mesh.triangles)
+        assert np.array_equal(lay.nodes, t[f"r{r}_local_nodes"])                 # rankwise_dist: first-touch order
+        assert np.array_equal(lay.elements, t[f"r{r}_local_elements"])
+        assert np.array_equal(lay.shared_nodes, t[f"r{r}_shared_nodes"])         # find_shared_nodes' order
+        assert np.array_equal(lay.dirichlet_dofs, t[f"r{r}_local_dirichlet"].astype(np.int64))  # Dirichlet_rank_dist
+        assert np.array_equal(gshared, t["Global_shared"])                       # sort_shared
+        assert np.array_equal(np.sort(dn), np.sort(s["dirichlet_nodes"]))        # Data_prepare.py:127-136
+        # derived lists the kernels also hand out: local ids of the shared nodes, their slots in Global_shared, local
+        # connectivity
+        pos = {int(g): i for i, g in enumerate(lay.nodes)}
+        assert np.array_equal(lay.shared_local, [pos[int(g)] for g in lay.shared_nodes])
+        assert np.array_equal(lay.shared_slots, np.searchsorted(t["Global_shared"], lay.shared_nodes))
+        assert np.array_equal(np.asarray(lay.nodes)[lay.cells_local], mesh.tets[lay.elements])
+    lay, gshared, dn = fs.device_rank_layout(mesh.tets, np.zeros(len(mesh.tets), dtype=np.int64), 0, 1, len(mesh.points), None,
+                                             mesh.points, mesh.triangles)
+    assert np.array_equal(lay.nodes, s["local_nodes"]) and np.array_equal(lay.elements, s["local_elements"])
+    assert np.array_equal(lay.dirichlet_dofs, s["local_dirichlet"]) and len(gshared) == 0
+    assert np.array_equal(np.sort(dn), np.sort(s["dirichlet_nodes"]))
 
 
 def test_reference_mesh_two_and_three_parts(beam_coarse):

@@ -46,4 +46,14 @@ graphs)
   run force_dev_kernarg_0 HIP_FORCE_DEV_KERNARG=0 python tools/graph_staleness.py
   run blit_kernarg_opt_off DEBUG_CLR_BLIT_KERNARG_OPT=0 python tools/graph_staleness.py
   ;;
+graphs2)
+  g=$out/graphs; mkdir -p $g
+  run() { name=$1; shift; timeout -k 10 240 env "$@" > $g/$name.txt 2>&1; echo "exit $?" >> $g/$name.txt; }
+  run step1               python tools/graph_staleness.py --step 1 --max 40
+  run mse_width8          python tools/graph_staleness.py --pass mse --width 8
+  run mse_width64         python tools/graph_staleness.py --pass mse --width 64
+  run train_graph         python tools/wide_lstm_check.py 9126 12 graph
+  run train_graph_nocapture DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 python tools/wide_lstm_check.py 9126 12 graph
+  run train_eager         python tools/wide_lstm_check.py 9126 12 eager
+  ;;
 esac

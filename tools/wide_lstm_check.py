@@ -21,10 +21,13 @@ j = torch.arange(width, dtype=torch.float64, device=dev)[None, :]
 hist = 1e-3 * t.clamp(max=1.0) ** 2 * (1.0 + 0.3 * torch.sin(40.0 * t + 0.01 * j)) * (1.0 + 1e-4 * j)
 torch.cuda.synchronize()
 t0 = time.time()
-model, smax, smin, tl, vl = tr.train_on_history(hist, n_s, n_p, n_f, seed=0, hidden_size=50, max_seconds=seconds)
+mode = sys.argv[3] if len(sys.argv) > 3 else "graph"  # "eager": the optimiser step launched kernel by kernel
+model, smax, smin, tl, vl = tr.train_on_history(hist, n_s, n_p, n_f, seed=0, hidden_size=50, max_seconds=seconds,
+                                                graph=(mode != "eager"))
 torch.cuda.synchronize()
 t1 = time.time()
-print(f"width {width}: {len(tl)} epochs in {t1 - t0:.1f} s ({(t1 - t0) / len(tl) * 1e3:.0f} ms per epoch of 13 batches), "
+print(f"[{mode}, DEBUG_CLR_GRAPH_PACKET_CAPTURE={os.environ.get('DEBUG_CLR_GRAPH_PACKET_CAPTURE', 'unset')}] "
+      f"width {width}: {len(tl)} epochs in {t1 - t0:.1f} s ({(t1 - t0) / len(tl) * 1e3:.0f} ms per epoch of 13 batches), "
       f"train MSE {tl[0]:.3e} -> {tl[-1]:.3e}, validation {vl[-1]:.3e}; "
       f"parameters {sum(p.numel() for p in model.parameters())}, peak memory {torch.cuda.max_memory_allocated() / 2**30:.2f} GiB")
 predictor = pr.DevicePredictor(model, n_p, n_f, n_s, smax, smin)
