@@ -1619,6 +1619,9 @@ int saa_predictor_predict(saa_predictor *p, const double *hist_dev, int64_t hist
   const int64_t window = (int64_t)sh.n_past * sh.filter;
   if (ld_hist < sh.input_size || ld_table < sh.input_size)
     return fail(SAA_E_ARG, "saa_predictor_predict: row stride below input_size");
+  // (the GEMM kernel forms a tile's row offsets in 32 bits: 63 rows of ld_hist doubles + one row's columns)
+  if (63 * ld_hist * 8 + (int64_t)sh.input_size * 8 >= (1ll << 31))
+    return fail(SAA_E_ARG, "saa_predictor_predict: history row stride too large (63 rows of it must stay below 2 GiB)");
   if (n < window || n > hist_rows)
     return fail(SAA_E_ARG, "saa_predictor_predict: rows [n - n_past*filter, n) are not inside the history");
   if (!(scale_max - scale_min != 0.0)) return fail(SAA_E_ARG, "saa_predictor_predict: scale_max == scale_min");

@@ -132,7 +132,7 @@ constexpr int kPairSyms[6][5] = {{0, 1, 2, 3, 4}, {0, 2, 3, 1, 4}, {0, 3, 1, 2, 
 // in: loc = 4 block-local node ids per element.  out: items (8 uint16 each); returns their number.
 // xl / h (optional): coordinates of the block-local nodes and the mesh size, for the shape classes below.
 int32_t build_items(const std::vector<uint16_t> &loc, int32_t n_elem, int32_t n_owned, std::vector<uint16_t> &items,
-                    const double *xl = nullptr, double h = 0.0) {
+                    const double *xl = nullptr, double h = 0.0, bool augment = false) {
   struct Face {
     uint64_t key;
     int32_t elem;
@@ -307,6 +307,17 @@ int32_t build_items(const std::vector<uint16_t> &loc, int32_t n_elem, int32_t n_
       return x < y;
     });
   }
+  // the matching first (mate / face of every element), the items afterwards
+  std::vector<int32_t> mate(n_elem, -1);
+  std::vector<int8_t> mface(n_elem, -1);
+  auto join = [&](int32_t e, int k) {
+    const int32_t f = nb[4 * static_cast<size_t>(e) + k];
+    mate[e] = f;
+    mface[e] = static_cast<int8_t>(k);
+    mate[f] = e;
+    mface[f] = static_cast<int8_t>(nbk[4 * static_cast<size_t>(e) + k]);
+  };
+  int32_t n_single = 0;
   for (int32_t e : order) {
     if (used[e]) continue;
     int best_k = -1, best_deg = 99;
@@ -325,11 +336,90 @@ int32_t build_items(const std::vector<uint16_t> &loc, int32_t n_elem, int32_t n_
       }
     }
     if (best_k >= 0) {
-      const int32_t f = nb[4 * static_cast<size_t>(e) + best_k];
-      emit_pair(e, best_k);
-      used[e] = used[f] = 1;
+      join(e, best_k);
+      used[e] = used[nb[4 * static_cast<size_t>(e) + best_k]] = 1;
     } else {
       used[e] = 1;
+      ++n_single;
+    }
+  }
+  // Unstructured meshes: the greedy pass leaves 5-10 % of the elements single (a Delaunay mesh of random points: 10 %),
+  // and a single costs a lane as much as a pair.  Augmenting paths of length three - single s, its neighbour f matched
+  // with g, g's other neighbour t single: (s,f) (g,t) instead of (f,g) - and, in a second sweep, of length five pick most
+  // of them up; here an all-owned element may also pair with one that has halo nodes (the item then waits for the halo
+  // records like its second element would have).  Only on request (`augment`: the caller asks when more than 4 % of a
+  // block's elements stayed single): on lattices (99.8 % paired) the pairing stays exactly what the pattern classes of
+  // the LDS packing were tuned on.
+  if (augment && n_single > 0) {
+    auto eligible = [&](int32_t e, int k) -> int32_t {  // partner(e, k) without the `used` and the class test
+      const int32_t f = nb[4 * static_cast<size_t>(e) + k];
+      if (f < 0) return -1;
+      uint16_t A[4], B[4];
+      apex_first(e, k, A);
+      apex_first(f, nbk[4 * static_cast<size_t>(e) + k], B);
+      return compatible(A, B) ? f : -1;
+    };
+    // a free (single) neighbour of g other than `avoid`, or -1
+    auto free_neighbour = [&](int32_t g, int32_t avoid, int &kk_out) -> int32_t {
+      for (int kk = 0; kk < 4; ++kk) {
+        const int32_t t = eligible(g, kk);
+        if (t < 0 || t == avoid || mate[t] >= 0) continue;
+        kk_out = kk;
+        return t;
+      }
+      return -1;
+    };
+    for (int sweep = 0; sweep < 3; ++sweep) {
+      int32_t gained = 0;
+      for (int32_t s0 : order) {
+        if (mate[s0] >= 0) continue;
+        bool done = false;
+        for (int k = 0; k < 4 && !done; ++k) {
+          const int32_t f = eligible(s0, k);
+          if (f < 0) continue;
+          if (mate[f] < 0) {  // two singles side by side (left by an earlier exchange)
+            join(s0, k);
+            done = true;
+            break;
+          }
+          const int32_t g = mate[f];
+          int kk = -1;
+          const int32_t t = free_neighbour(g, s0, kk);
+          if (t >= 0) {  // length three
+            join(s0, k);
+            join(g, kk);
+            done = true;
+            break;
+          }
+          if (sweep == 0) continue;
+          // length five: g's other neighbours u, matched with v, and v has a free neighbour w
+          for (int k2 = 0; k2 < 4 && !done; ++k2) {
+            const int32_t u = eligible(g, k2);
+            if (u < 0 || u == f || mate[u] < 0) continue;
+            const int32_t v = mate[u];
+            if (v == s0 || v == f || v == g) continue;
+            int k3 = -1;
+            const int32_t w = free_neighbour(v, s0, k3);
+            if (w < 0 || w == g || w == f || w == u) continue;
+            join(s0, k);
+            join(g, k2);
+            join(v, k3);
+            done = true;
+          }
+        }
+        gained += done;
+      }
+      if (gained == 0) break;
+    }
+  }
+  std::vector<char> out_done(n_elem, 0);
+  for (int32_t e : order) {
+    if (out_done[e]) continue;
+    out_done[e] = 1;
+    if (mate[e] >= 0) {
+      out_done[mate[e]] = 1;
+      emit_pair(e, mface[e]);
+    } else {
       emit_single(e);
     }
   }
@@ -746,6 +836,210 @@ void relabel_owned(uint16_t *items, int32_t n, int32_t n_owned, const std::vecto
     for (int a = 0; a < (it[5] ? 5 : 4); ++a)
       if (it[a] < n_owned) it[a] = pi[it[a]];
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Joint numbering and packing for blocks without lattice structure
+// ------------------------------------------------------------------------------------------------
+// Worst bank multiplicities of a packed list as the kernels will meet them (indices as they stand): per half-wave and
+// vertex slot the reads of either 16-lane group (index mod 16) and the atomics of the half (owned indices mod 32).
+void measure_pack(const uint16_t *list, int32_t n_slots, int32_t n_owned, PackStats &st) {
+  for (int32_t base = 0; base < n_slots; base += 32) {
+    uint8_t cnt_rd[2][5][16] = {}, cnt_at[5][32] = {};
+    int max_rd[2][5] = {}, max_at[5] = {};
+    for (int g = 0; g < 2; ++g)
+      for (int j = 0; j < 16; ++j) {
+        const int32_t sl = base + kGroupLanes[g][j];
+        if (sl >= n_slots) continue;
+        const uint16_t *it = list + 8 * static_cast<size_t>(sl);
+        if (it[5] == 2) continue;
+        const int real = it[5] ? 5 : 4;
+        for (int a = 0; a < real; ++a) {
+          max_rd[g][a] = std::max<int>(max_rd[g][a], ++cnt_rd[g][a][it[a] & 15]);
+          if (it[a] < n_owned) max_at[a] = std::max<int>(max_at[a], ++cnt_at[a][it[a] & 31]);
+        }
+      }
+    for (int a = 0; a < 5; ++a) {
+      for (int g = 0; g < 2; ++g)
+        if (max_rd[g][a] > 0) {
+          st.read_mult += max_rd[g][a];
+          ++st.read_cnt;
+        }
+      if (max_at[a] > 0) {
+        st.atomic_mult += max_at[a];
+        ++st.atomic_cnt;
+      }
+    }
+  }
+}
+
+// A mesh without lattice structure has no pattern classes, and with ANY numbering fixed beforehand the greedy packing of
+// reorder_for_lds runs into the same wall: the last lanes of a 16-lane group need one specific bank residue in each of five
+// vertex slots, and among a few thousand items with effectively random residues there is none (14 lanes fill clash-free,
+// the 15th in two cases of five, the 16th never: read conflict factor 1.7 on a Delaunay mesh whatever the numbering).  What
+// can still be chosen when those lanes are filled is the residue of a node that has not appeared yet.  So here the
+// numbering is decided WHILE the groups are formed: a node's residue (local index mod 32) is fixed the first time an item
+// that names it is placed, as whatever the group it joins has free; items all of whose nodes are fixed go first, items
+// with free nodes fill the lanes that nothing else fits.  Lists `n_list` are packed one after the other with one shared
+// numbering (the first round, then the rest).  Out: per owned node and per halo position the residue chosen (assign_by_colour
+// turns them into indices), and the packed lists in the OLD indices (the caller renames them).
+struct JointState {
+  int32_t n_owned = 0, n_halo = 0;
+  std::vector<int8_t> res;        // per local node: residue 0..31, -1 = free
+  int32_t room_owned[32], room_halo[32];
+};
+
+int32_t joint_pack_list(const uint16_t *items, int32_t n_items, JointState &js, std::vector<uint16_t> &out) {
+  constexpr int kHalf = 32, kSlots = 5, kWindow = 1024;
+  out.clear();
+  if (n_items <= 0) return 0;
+  const int32_t n_owned = js.n_owned;
+  std::vector<int32_t> pool(n_items);
+  std::iota(pool.begin(), pool.end(), 0);
+  auto n_syms = [](const uint16_t *it) { return it[5] ? 6 : 12; };
+  auto relabel = [](const uint16_t *it, int q, uint16_t v[5]) {
+    if (it[5]) {
+      for (int a = 0; a < kSlots; ++a) v[a] = it[kPairSyms[q][a]];
+    } else {
+      for (int a = 0; a < 4; ++a) v[a] = it[kEvenPerms[q][a]];
+      v[4] = v[1];
+    }
+  };
+  int32_t done = 0, remaining = n_items;
+  while (remaining > 0) {
+    out.resize(8 * static_cast<size_t>(done + kHalf), 0);
+    for (int32_t l = 0; l < kHalf; ++l) out[8 * static_cast<size_t>(done + l) + 5] = 2;
+    int used[2] = {0, 0};
+    uint32_t taken_rd[2][kSlots] = {}, taken_at[kSlots] = {};
+    uint8_t cnt_rd[2][kSlots][16] = {}, cnt_at[kSlots][32] = {};
+    int max_rd[2][kSlots] = {}, max_at[kSlots] = {};
+    int32_t placed = 0;
+    // a residue for the free node `v` in slot a of group g: room left in its class, bank free for the group's reads and,
+    // if owned, for the half's atomics; the class with most room left (keeps the classes level).  -1: none.
+    auto pick = [&](uint16_t v, int g, int a) -> int {
+      const bool owned = v < n_owned;
+      const int32_t *room = owned ? js.room_owned : js.room_halo;
+      int best = -1, best_room = 0;
+      for (int c = 0; c < 32; ++c) {
+        if (room[c] <= best_room) continue;
+        if ((taken_rd[g][a] >> (c & 15)) & 1u) continue;
+        if (owned && ((taken_at[a] >> c) & 1u)) continue;
+        best = c;
+        best_room = room[c];
+      }
+      return best;
+    };
+    auto put = [&](int32_t pool_pos, int q, int g, const int *chosen) {  // chosen[a]: residue for a free node in slot a, or -1
+      const uint16_t *it = items + 8 * static_cast<size_t>(pool[pool_pos]);
+      uint16_t v[5];
+      relabel(it, q, v);
+      const int32_t lane = kGroupLanes[g][used[g]++];
+      uint16_t *dst = &out[8 * static_cast<size_t>(done + lane)];
+      const int real = it[5] ? 5 : 4;
+      for (int a = 0; a < kSlots; ++a) {
+        dst[a] = v[a];
+        if (a >= real) continue;
+        if (js.res[v[a]] < 0) {
+          int c = chosen ? chosen[a] : -1;
+          if (c < 0) {  // forced placement: the class with most room, clash or not
+            const int32_t *room = v[a] < n_owned ? js.room_owned : js.room_halo;
+            c = 0;
+            for (int k = 1; k < 32; ++k)
+              if (room[k] > room[c]) c = k;
+          }
+          js.res[v[a]] = static_cast<int8_t>(c);
+          --(v[a] < n_owned ? js.room_owned : js.room_halo)[c];
+        }
+        const int c = js.res[v[a]];
+        taken_rd[g][a] |= 1u << (c & 15);
+        max_rd[g][a] = std::max<int>(max_rd[g][a], ++cnt_rd[g][a][c & 15]);
+        if (v[a] < n_owned) {
+          taken_at[a] |= 1u << c;
+          max_at[a] = std::max<int>(max_at[a], ++cnt_at[a][c]);
+        }
+      }
+      dst[5] = it[5];
+      ++placed;
+      --remaining;
+      pool[pool_pos] = -1;
+    };
+    const int32_t lim = std::min<int32_t>(static_cast<int32_t>(pool.size()), kWindow);
+    // clash-free placements: first the items whose nodes are all fixed (sweep 0), then those with one free node, two, ...
+    for (int sweep = 0; sweep <= 5 && placed < kHalf; ++sweep)
+      for (int32_t p = 0; p < lim && placed < kHalf; ++p) {
+        if (pool[p] < 0) continue;
+        const uint16_t *it = items + 8 * static_cast<size_t>(pool[p]);
+        const int real = it[5] ? 5 : 4;
+        int n_free = 0;
+        for (int a = 0; a < real; ++a) n_free += js.res[it[a]] < 0;
+        if (n_free != sweep) continue;
+        bool ok = false;
+        for (int q = 0; q < n_syms(it) && !ok; ++q) {
+          uint16_t v[5];
+          relabel(it, q, v);
+          for (int g = 0; g < 2 && !ok; ++g) {
+            if (used[g] >= 16) continue;
+            int chosen[5] = {-1, -1, -1, -1, -1};
+            bool fits = true;
+            for (int a = 0; a < real && fits; ++a) {
+              const int c = js.res[v[a]];
+              if (c >= 0) {
+                if ((taken_rd[g][a] >> (c & 15)) & 1u) fits = false;
+                if (v[a] < n_owned && ((taken_at[a] >> c) & 1u)) fits = false;
+              } else {
+                chosen[a] = pick(v[a], g, a);
+                if (chosen[a] < 0) fits = false;
+              }
+            }
+            if (!fits) continue;
+            put(p, q, g, chosen);
+            ok = true;
+          }
+        }
+      }
+    // the rest where it raises the worst multiplicities least (free nodes cost nothing: they take a free bank if any)
+    while (placed < kHalf && remaining > 0) {
+      int32_t best_p = -1, best_q = 0, best_g = 0, best_k = 1 << 30;
+      for (int32_t p = 0; p < lim && best_k > 0; ++p) {
+        if (pool[p] < 0) continue;
+        const uint16_t *it = items + 8 * static_cast<size_t>(pool[p]);
+        const int real = it[5] ? 5 : 4;
+        for (int q = 0; q < n_syms(it) && best_k > 0; ++q) {
+          uint16_t v[5];
+          relabel(it, q, v);
+          for (int g = 0; g < 2; ++g) {
+            if (used[g] >= 16) continue;
+            int k = 0;
+            for (int a = 0; a < real; ++a) {
+              const int c = js.res[v[a]];
+              if (c < 0) continue;
+              if (cnt_rd[g][a][c & 15] + 1 > max_rd[g][a]) k += 12;
+              if (v[a] < n_owned && cnt_at[a][c] + 1 > max_at[a]) k += 21;
+            }
+            if (k < best_k) {
+              best_k = k;
+              best_p = p;
+              best_q = q;
+              best_g = g;
+            }
+          }
+        }
+      }
+      // free nodes of the forced item: a free bank where there is one
+      const uint16_t *it = items + 8 * static_cast<size_t>(pool[best_p]);
+      uint16_t v[5];
+      relabel(it, best_q, v);
+      int chosen[5] = {-1, -1, -1, -1, -1};
+      for (int a = 0; a < (it[5] ? 5 : 4); ++a)
+        if (js.res[v[a]] < 0) chosen[a] = pick(v[a], best_g, a);
+      put(best_p, best_q, best_g, chosen);
+    }
+    pool.erase(std::remove(pool.begin(), pool.begin() + lim, -1), pool.begin() + lim);
+    done += kHalf;
+  }
+  while (done > 0 && out[8 * static_cast<size_t>(done - 1) + 5] == 2) --done;
+  out.resize(8 * static_cast<size_t>(done));
+  return done;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1237,7 +1531,7 @@ bool build_once(int32_t n_nodes, int32_t n_elems, const double *xyz, const int32
   const char *lat_env = diag_env("SAA_PLAN_LATTICE_ORDERS");
   const bool lattice_orders = !(lat_env && lat_env[0] == '0');
   std::atomic<int32_t> renumbered{0};
-  std::atomic<int32_t> q_hist[12] = {};
+  std::atomic<int32_t> q_hist[13] = {};
   const char *alt_env = diag_env("SAA_PLAN_FIXED_AXES");
   const bool alt_axes = !(alt_env && alt_env[0] == '1');
   // One block per CU and 1024-thread workgroups (api: pick_threads): the resident kernel runs a block's first 1024
@@ -1283,9 +1577,21 @@ bool build_once(int32_t n_nodes, int32_t n_elems, const double *xyz, const int32
       int32_t ni = build_items(loc_b, ne, d.n_owned, items);
       if (shape_pairs && h_mesh > 0.0) {
         const int32_t ni_s = build_items(loc_b, ne, d.n_owned, items_s, xl.data(), h_mesh);
+        bool spatial = false;
         if (100 * static_cast<int64_t>(ni_s) < 99 * static_cast<int64_t>(ni)) {
           items.swap(items_s);
           ni = ni_s;
+          spatial = true;
+        }
+        // an unstructured mesh (more than 4 % of the block's elements single either way): the same matching improved by
+        // augmenting paths
+        if (200 * static_cast<int64_t>(ni) > 104 * static_cast<int64_t>(ne)) {
+          const int32_t ni_a = spatial ? build_items(loc_b, ne, d.n_owned, items_s, xl.data(), h_mesh, true)
+                                       : build_items(loc_b, ne, d.n_owned, items_s, nullptr, 0.0, true);
+          if (ni_a < ni) {
+            items.swap(items_s);
+            ni = ni_a;
+          }
         }
       }
       // interior items (every real vertex owned) first: they can run before the halo records arrive
@@ -1369,6 +1675,61 @@ bool build_once(int32_t n_nodes, int32_t n_elems, const double *xyz, const int32
           }
         }
       }
+      // no lattice structure to speak of (less than 30 % of the items in classes under the best numbering so far): the
+      // numbering decided while the groups are formed (joint_pack_list)
+      if (alt_axes && ni >= 256 &&
+          10 * (best.si.by_construction + best.sb.by_construction) < 3 * static_cast<int64_t>(best.mi + best.mb)) {
+        const double cost0 = best.cost;
+        JointState js;
+        js.n_owned = d.n_owned;
+        js.n_halo = d.n_halo;
+        js.res.assign(static_cast<size_t>(d.n_owned + d.n_halo), -1);
+        for (int c = 0; c < 32; ++c) {
+          js.room_owned[c] = c < d.n_owned ? (d.n_owned - c + 31) / 32 : 0;
+          js.room_halo[c] = 0;
+        }
+        for (int32_t i = d.n_owned; i < d.n_owned + d.n_halo; ++i) ++js.room_halo[i & 31];
+        cand.pio.clear();
+        cand.pih.clear();
+        cand.mi = joint_pack_list(out.data(), n_in, js, cand.pa);
+        cand.mb = joint_pack_list(out.data() + 8 * static_cast<size_t>(n_in), ni - n_in, js, cand.pb);
+        auto colours = [&](int32_t first, int32_t n, int32_t *room, std::vector<int> &col) {
+          col.resize(n);
+          for (int32_t l = 0; l < n; ++l) {
+            int c = js.res[first + l];
+            if (c < 0) {  // never named by an item: wherever there is room
+              c = 0;
+              for (int k = 1; k < 32; ++k)
+                if (room[k] > room[c]) c = k;
+              --room[c];
+            }
+            col[l] = c;
+          }
+        };
+        std::vector<int> col;
+        colours(0, d.n_owned, js.room_owned, col);
+        assign_by_colour(col, 0, cand.pio);
+        if (d.n_halo > 0) {
+          colours(d.n_owned, d.n_halo, js.room_halo, col);
+          assign_by_colour(col, d.n_owned, cand.pih);
+        }
+        for (std::vector<uint16_t> *lst : {&cand.pa, &cand.pb}) {
+          const int32_t m = static_cast<int32_t>(lst->size() / 8);
+          // (halo first: both renamings keep a vertex on its side of n_owned)
+          if (!cand.pih.empty()) relabel_halo(lst->data(), m, d.n_owned, cand.pih);
+          relabel_owned(lst->data(), m, d.n_owned, cand.pio);
+        }
+        cand.si = PackStats();
+        cand.sb = PackStats();
+        measure_pack(cand.pa.data(), cand.mi, d.n_owned, cand.si);
+        measure_pack(cand.pb.data(), cand.mb, d.n_owned, cand.sb);
+        cand.cost = 12.0 * (cand.si.read_mult + cand.sb.read_mult - cand.si.read_cnt - cand.sb.read_cnt) +
+                    21.0 * (cand.si.atomic_mult + cand.sb.atomic_mult - cand.si.atomic_cnt - cand.sb.atomic_cnt);
+        if (cand.cost < 0.97 * cost0) {
+          std::swap(best, cand);
+          best_q = 12;
+        }
+      }
       if (!best.pio.empty()) block_perm[b] = best.pio;
       if (!best.pih.empty()) block_halo_perm[b] = best.pih;
       renumbered += best_q >= 6;
@@ -1412,7 +1773,7 @@ bool build_once(int32_t n_nodes, int32_t n_elems, const double *xyz, const int32
     std::copy(moved.begin(), moved.end(), seg);
   }
   if (diag_env("SAA_PLAN_DEBUG")) {
-    fprintf(stderr, "plan: %d of %d blocks took a pseudo-lattice numbering; blocks per numbering 0..11:", renumbered.load(), n_blocks);
+    fprintf(stderr, "plan: %d of %d blocks took a pseudo-lattice numbering; blocks per numbering 0..12 (12: decided while packing):", renumbered.load(), n_blocks);
     for (auto &h : q_hist) fprintf(stderr, " %d", h.load());
     fprintf(stderr, "\n");
   }

@@ -740,9 +740,18 @@ hipError_t predictor_create(int device, const PredictorShape &sh, const float *c
     err = "saa_predictor_create: filter (n_s) must be at least 2";
     return hipErrorInvalidValue;
   }
-  if ((int64_t)sh.n_past * sh.filter * I * 8 >= (1ll << 31) || (int64_t)std::max(I, G) * (round_up(std::max(I, D), kKC)) * 4 >= (1ll << 31)) {
-    err = "saa_predictor_create: window too large (n_past * filter * input_size * 8 bytes must stay below 2 GiB)";
-    return hipErrorInvalidValue;
+  // What the GEMM kernel addresses with 32-bit lane offsets (gemm_nt_kernel: arow / brow + the column part) must stay
+  // below 2^31 bytes: a tile's rows of the fp64 history (kBM - 1 rows of ld_hist doubles + K doubles; ld_hist is checked
+  // again at predict time, here with the smallest stride possible, I), of the weights (kBN - 1 rows of ldbI resp. ldbD
+  // floats + one chunk) and of the hidden states.  That allows input sizes up to ~2.5 M (a partition with 860 000 shared
+  // nodes); the arrays themselves are addressed with 64-bit bases.
+  {
+    const int64_t ldbI = round_up(I, kKC), ldbD = round_up(D, kKC), lim = 1ll << 31;
+    if ((int64_t)(kBM - 1) * I * 8 + (int64_t)I * 8 >= lim || (int64_t)(kBN - 1) * ldbI * 4 + 4 * kKC >= lim ||
+        (int64_t)(kBN - 1) * ldbD * 4 + 4 * kKC >= lim || (int64_t)(kBM - 1) * ldbD * 4 + 4 * (int64_t)D >= lim) {
+      err = "saa_predictor_create: input_size too large for the 32-bit tile offsets of the GEMM kernel (limit ~2.5 million)";
+      return hipErrorInvalidValue;
+    }
   }
   if (G > 1024) {
     err = "saa_predictor_create: hidden size above 128 is not supported (one thread per gate row)";

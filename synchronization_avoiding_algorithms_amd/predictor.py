@@ -218,6 +218,12 @@ class NativePredictor:
             pass
 
 
+def _lib_error():
+    from . import _lib
+
+    return _lib.SaaError
+
+
 class DevicePredictor:
     """Callable for :func:`distributed.run_hybrid`: keeps model and scaling on the solver's device.
 
@@ -278,7 +284,16 @@ class DevicePredictor:
     def __call__(self, n, hist):
         if self._use_native and hist.is_cuda:
             if self._native is None or self._native.device_index != hist.device.index:
-                self._native = NativePredictor(self.model, self.n_p, self.n_f, self.n_s, hist.device.index)
+                try:
+                    self._native = NativePredictor(self.model, self.n_p, self.n_f, self.n_s, hist.device.index)
+                except (_lib_error(), ValueError) as exc:
+                    # a shape the library's kernels do not take (hidden size above 128, n_past * hidden beyond one
+                    # workgroup's LDS, ...): said once, then the PyTorch-ROCm route, which takes any shape
+                    import warnings
+
+                    warnings.warn(f"native predictor refused this model ({exc}); using the PyTorch-ROCm route")
+                    self._use_native = False
+                    return self(n, hist)
                 self._native_table = torch.empty((self.n_s * self.n_f, hist.shape[1]), dtype=torch.float64,
                                                  device=hist.device)
             return self._native.predict(n, hist, self.scale_max, self.scale_min, self._native_table)

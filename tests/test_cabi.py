@@ -84,3 +84,26 @@ def test_synthetic_beam_shapes():
     assert len(clamp_nodes(m)) == 9
     lumped, load = fs.lumped_mass_and_load(m.points, m.tets, 1.0, 0.5)
     assert np.isclose(lumped.sum() / 3, 25.0) and np.allclose(load.reshape(-1, 3).sum(0), [0, -12.5, -12.5])
+
+
+def test_predictor_size_bounds_are_the_ones_the_kernels_index_with():
+    """saa_predictor_create validates the shape before it touches a device: an input size whose 32-bit tile offsets would
+    overflow is refused with a clear message, while the width of a large k-way partition (30 000 inputs = 10 000 shared
+    nodes; round 3 refused everything above 23 170) passes the validation and only then fails for want of a GPU."""
+    import ctypes as C
+
+    from synchronization_avoiding_algorithms_amd import _lib
+
+    lib = _lib.load()
+    dummy = (C.c_float * 4)()
+    ptrs = (C.POINTER(C.c_float) * 22)(*[C.cast(dummy, C.POINTER(C.c_float))] * 22)
+    h = C.c_void_p()
+    rc = lib.saa_predictor_create(0, 3_000_000, 50, 20, 20, 150, ptrs, 22, C.byref(h))
+    assert rc == _lib.SAA_E_ARG and b"input_size too large" in lib.saa_last_error()
+    rc = lib.saa_predictor_create(0, 5, 200, 20, 20, 150, ptrs, 22, C.byref(h))
+    assert rc == _lib.SAA_E_ARG and b"hidden size above 128" in lib.saa_last_error()
+    import torch
+
+    if not torch.cuda.is_available():  # (on a GPU box this would go on to read 30 000-wide weights from the dummy)
+        rc = lib.saa_predictor_create(0, 30_000, 50, 20, 20, 150, ptrs, 22, C.byref(h))
+        assert rc == _lib.SAA_E_HIP, (rc, lib.saa_last_error())  # past the shape checks: only the device is missing

@@ -182,6 +182,41 @@ def test_one_million_tets_with_jittered_nodes_and_shuffled_numbering():
     sol.close()
 
 
+def test_one_million_tets_of_a_delaunay_mesh():
+    """The workload of ``bench.py --mesh delaunay`` / the `unstructured` leg of the N = 1 line: the beam's box meshed by a
+    Delaunay triangulation of random points (mesh.delaunay_beam: no lattice anywhere, valences 2...47, the class of mesh the
+    reference's Gmsh input is, Mesh_info/beam_US.geo:2-16) - elements paired by augmenting paths, block nodes numbered
+    while the LDS groups are formed (saa_plan.cpp: joint_pack_list).  Operator properties and 100 steps of both kernels
+    against the oracle's element-by-element operator on that mesh."""
+    from oracle import fem_oracle as fo
+    from synchronization_avoiding_algorithms_amd.mesh import delaunay_beam
+
+    mesh = delaunay_beam(19)
+    assert len(mesh.points) == 190400 and len(mesh.tets) > 1000000
+    sol, lay, dt, l_M, F, (lmd, mu) = _build(mesh, 1, 0)
+    st = sol.plan_stats()
+    assert st["n_blocks"] == 256 and sol.resident_kernel_info()["capable"]
+    assert st["n_by_construction"] == 0 and st["n_renumbered"] == 256            # nothing a lattice numbering could use
+    assert st["n_pairs"] > 0.97 * st["n_elem_copies"] / 2 and st["lds_conflict_factor"] < 1.5, st
+    K = fo.MatrixFreeStiffness(lay.cells_local, mesh.points[lay.nodes], lmd, mu)
+    rng = np.random.default_rng(11)
+    _operator_properties(sol, K, mesh.points[lay.nodes], rng)
+    d0, dn = _rough_state(sol.n_dof, lay.dirichlet_dofs, rng)
+    d0, dn = 1e-2 * d0, 1e-2 * dn  # (elements down to 1/500 of the mean volume: keep the start inside the linear range)
+    tn, o0, on = 0.25, d0, dn
+    for _ in range(100):
+        o1 = fo.explicit_step(K, F, lay.dirichlet_dofs, tn, dt, o0, on, l_M, ALPHA)
+        on, o0, tn = o0, o1, tn + dt
+    assert np.isfinite(o0).all() and np.abs(o0).max() < 1.0
+    for name, resident in (("resident", True), ("fused", False)):
+        sol.set_resident_kernel(resident)
+        sol.set_state(d0, dn, 0.25)
+        sol.step(100)
+        g0, gn, gt = sol.get_state()
+        assert gt == tn and rel_l2(g0, o0) < 1e-11 and rel_l2(gn, on) < 1e-11, name
+    sol.close()
+
+
 def test_config3_middle_slab_of_the_8gpu_partition_through_the_peer_exchange(middle_slab):
     import torch
     from oracle import fem_oracle as fo
