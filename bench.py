@@ -998,6 +998,8 @@ def main():
     ap.add_argument("--preflight", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--force-preflight", action="store_true", help=argparse.SUPPRESS)  # tests: preflight with --same-device
     ap.add_argument("--force-rccl-leg", action="store_true", help=argparse.SUPPRESS)   # tests: the RCCL leg on gloo
+    ap.add_argument("--preflight-limit-s", type=float, default=90.0, help=argparse.SUPPRESS)  # cap of the preflight child
+    ap.add_argument("--rccl-leg-limit-s", type=float, default=90.0, help=argparse.SUPPRESS)   # cap of the RCCL leg
     ap.add_argument("--min-timed-ms", type=float, default=1000.0,
                     help="the timed call of --steps steps is repeated until the timed region lasts at least this long; "
                          "the legs of the N = 1 line time regions of the same length")
@@ -1026,7 +1028,7 @@ def main():
     exchange = "torch" if args.torch_exchange else args.exchange
     peer_ok = True
     if world > 1 and exchange == "auto" and (not args.same_device or args.force_preflight):
-        limit = min(90.0, 0.25 * max(legs.left(), 0.0))
+        limit = min(args.preflight_limit_s, 0.25 * max(legs.left(), 0.0))
         legs.begin("preflight")
         peer_ok = run_preflight(args, world, limit)
         legs.end("preflight", "done" if peer_ok else f"failed or exceeded {limit:.0f} s: all-reduce instead of the peer exchange")
@@ -1187,7 +1189,7 @@ def main():
     # measured with the peer exchange, the same partitions are stepped once more with ncclAllReduce issued from C++
     # (saa_step_synced) and reported next to it.
     if rccl_wanted:
-        limit = min(90.0, legs.left() - 12.0)
+        limit = min(args.rccl_leg_limit_s, legs.left() - 12.0)
         t = torch.tensor([limit], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         limit = float(t.item())

@@ -46,30 +46,6 @@ def local_mat_node(G_ID, L_N):
     return order[pos].tolist()
 
 
-_MULTI_HOLDER_CACHE = {}
-
-
-def _multi_holder_dofs(size, rank, L_g, Local_nodes, device, group):
-    """Global dofs of the nodes held by THREE or more ranks (one collective, cached per node list): the only places where
-    the order of a sum over the ranks matters (a + b == b + a, but (a + b) + c is not a + (b + c))."""
-    import torch
-    import torch.distributed as dist
-
-    nodes = np.asarray(Local_nodes, dtype=np.int64)
-    key = (size, rank, int(L_g), str(device), nodes.tobytes())
-    hit = _MULTI_HOLDER_CACHE.get(key)
-    if hit is None:
-        cnt = torch.zeros(int(L_g), dtype=torch.int32, device=device)
-        cnt[torch.as_tensor(nodes, device=device)] = 1
-        dist.all_reduce(cnt, group=group)
-        multi = torch.nonzero(cnt >= 3).reshape(-1)
-        hit = (3 * multi[:, None] + torch.arange(3, device=device)[None, :]).reshape(-1)
-        if len(_MULTI_HOLDER_CACHE) > 16:
-            _MULTI_HOLDER_CACHE.clear()
-        _MULTI_HOLDER_CACHE[key] = hit
-    return hit
-
-
 def syn_cpus(size, rank, f, L_g, Local_nodes, group=None):
     """Sum of every rank's local force vector on the global numbering, restricted back
     (``Distributed_tools.py:77-92``).  One ``all_reduce`` instead of gather + root add + bcast; must be
@@ -84,10 +60,18 @@ def syn_cpus(size, rank, f, L_g, Local_nodes, group=None):
     dof = node_to_dof(3, [0, 1, 2], Local_nodes)
 
     def reduce_in_rank_order(g):
+        # the holder count of every node rides along in the same all-reduce (L_g more values): which dofs have three or
+        # more holders is then known to every rank from the SAME reduced data in the SAME call - no cache, no second
+        # collective whose entry could depend on a rank's history
         local = g.clone()
-        dist.all_reduce(g, group=group)
-        multi = _multi_holder_dofs(size, rank, L_g, Local_nodes, g.device, group)
-        if multi.numel() > 0:
+        idx_nodes = torch.as_tensor(np.asarray(Local_nodes, dtype=np.int64), device=g.device)
+        buf = torch.cat((g.reshape(-1), torch.zeros(int(L_g), dtype=g.dtype, device=g.device)))
+        buf[3 * int(L_g) + idx_nodes] = 1.0
+        dist.all_reduce(buf, group=group)
+        g = buf[:3 * int(L_g)].reshape(-1, 1).clone()
+        multi_nodes = torch.nonzero(buf[3 * int(L_g):] >= 3).reshape(-1)  # (small integers: exact in floating point)
+        if multi_nodes.numel() > 0:  # the same decision on every rank
+            multi = (3 * multi_nodes[:, None] + torch.arange(3, device=g.device)[None, :]).reshape(-1)
             parts = [torch.empty((multi.numel(), 1), dtype=g.dtype, device=g.device) for _ in range(size)]
             dist.all_gather(parts, local[multi].contiguous(), group=group)
             acc = torch.zeros_like(parts[0])

@@ -21,7 +21,9 @@
 // gfx950 anyway).  64-wide waves; cross-workgroup data flows through kernel boundaries (cross-RANK data of the
 // PEER variant through self-validating entries in fine-grained memory).
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cstddef>
+#include <cstdlib>
 #include <stdint.h>
 
 #include "saa_device.h"
@@ -362,6 +364,8 @@ __device__ __forceinline__ double peer_collect(const PeerMap *pm, const PeerRecv
 
 // ABLATE (diagnostic builds only, never launched by the product path): 1 = no LDS atomics,
 // 2 = no indexed LDS reads, 3 = no staging loads, 4 = no update phase, 5 = no element phase.
+// 10 = 3 and 4 together: the element phase alone with its real LDS traffic (what a workgroup whose memory phases were
+// hidden completely would still take).
 // PEER: synchronised step with the direct peer exchange - shared nodes are pushed to / collected from the
 // neighbour ranks inside this kernel (one launch per step, no collective).
 template <bool FORCE_ONLY, int ABLATE = 0, bool PEER = false>
@@ -410,8 +414,8 @@ __global__ void __launch_bounds__(SAA_LB) fused_step_kernel(DeviceMesh m, const 
     const double *uo = d0 + base;
     for (int i = tid; i < n_own3; i += nt) {
       const int n = i / 3, c = i - 3 * n;
-      rec[6 * n + c] = ABLATE == 3 ? 1.0 * i : xo[i];
-      rec[6 * n + 3 + c] = ABLATE == 3 ? 1e-3 * i : uo[i];
+      rec[6 * n + c] = (ABLATE == 3 || ABLATE == 10) ? 1.0 * i : xo[i];
+      rec[6 * n + 3 + c] = (ABLATE == 3 || ABLATE == 10) ? 1e-3 * i : uo[i];
       acc[3 * n + c] = 0.0;
     }
   }
@@ -420,8 +424,8 @@ __global__ void __launch_bounds__(SAA_LB) fused_step_kernel(DeviceMesh m, const 
   double hx[kPreHalo], hu[kPreHalo];
 #pragma unroll
   for (int j = 0; j < kPreHalo; ++j) {
-    hx[j] = ABLATE == 3 ? 1.0 * tid : m.xyz[hg[j]];
-    hu[j] = ABLATE == 3 ? 1e-3 * tid : d0[hg[j]];
+    hx[j] = (ABLATE == 3 || ABLATE == 10) ? 1.0 * tid : m.xyz[hg[j]];
+    hu[j] = (ABLATE == 3 || ABLATE == 10) ? 1e-3 * tid : d0[hg[j]];
   }
   double pm_[kPreOwn], pf[kPreOwn], pn[kPreOwn];
   int32_t ptag[kPreOwn];
@@ -429,10 +433,10 @@ __global__ void __launch_bounds__(SAA_LB) fused_step_kernel(DeviceMesh m, const 
 #pragma unroll
     for (int j = 0; j < kPreOwn; ++j) {
       const int i = min(tid + j * nt, n_own3 - 1);
-      pm_[j] = ABLATE == 4 ? 1.0 : (m.mass_node ? m.mass_node[bd.node_start + i / 3] : m.mass[base + i]);
-      pf[j] = ABLATE == 4 ? 0.0 : (m.fext_yz ? (i % 3 == 0 ? 0.0 : m.fext_yz[bd.node_start + i / 3]) : m.fext[base + i]);
-      pn[j] = ABLATE == 4 ? 0.0 : dn[base + i];
-      ptag[j] = ABLATE == 4 ? 0 : m.tag[bd.node_start + i / 3];
+      pm_[j] = (ABLATE == 4 || ABLATE == 10) ? 1.0 : (m.mass_node ? m.mass_node[bd.node_start + i / 3] : m.mass[base + i]);
+      pf[j] = (ABLATE == 4 || ABLATE == 10) ? 0.0 : (m.fext_yz ? (i % 3 == 0 ? 0.0 : m.fext_yz[bd.node_start + i / 3]) : m.fext[base + i]);
+      pn[j] = (ABLATE == 4 || ABLATE == 10) ? 0.0 : dn[base + i];
+      ptag[j] = (ABLATE == 4 || ABLATE == 10) ? 0 : m.tag[bd.node_start + i / 3];
     }
   }
   lds_barrier();
@@ -534,7 +538,7 @@ __global__ void __launch_bounds__(SAA_LB) fused_step_kernel(DeviceMesh m, const 
     T[10] = t - tk;  // waiting for the slowest wave
     tk = t;
   }
-  if (ABLATE == 4) {
+  if (ABLATE == 4 || ABLATE == 10) {
     if (tid == 0) out[base] = acc[0];
     return;
   }
@@ -1330,6 +1334,8 @@ void launch_fused_step_ablated(int variant, const DeviceMesh &m, int threads, in
                                const double *d0, const double *dn, double *d1, const StepConsts &k, double *dbg) {
   double *none = nullptr;
   const double *cnone = nullptr;
+  // SAA_ABLATE_EXTRA_LDS (bytes): unused dynamic LDS on top of the image, e.g. to leave room for ONE workgroup per CU only
+  if (const char *env = getenv("SAA_ABLATE_EXTRA_LDS")) lds_bytes = std::min(160 * 1024, lds_bytes + atoi(env));
 #define SAA_ABL(V)                                                                                         \
   case V:                                                                                                  \
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_step_kernel<false, V>),                \
@@ -1338,7 +1344,7 @@ void launch_fused_step_ablated(int variant, const DeviceMesh &m, int threads, in
                        dn, d1, none, cnone, V == 8 ? dbg : none, k, static_cast<const PeerMap *>(nullptr), 0u, cnone); \
     break;
   switch (variant) {
-    SAA_ABL(0) SAA_ABL(1) SAA_ABL(2) SAA_ABL(3) SAA_ABL(4) SAA_ABL(5) SAA_ABL(6) SAA_ABL(7) SAA_ABL(8) SAA_ABL(9)
+    SAA_ABL(0) SAA_ABL(1) SAA_ABL(2) SAA_ABL(3) SAA_ABL(4) SAA_ABL(5) SAA_ABL(6) SAA_ABL(7) SAA_ABL(8) SAA_ABL(9) SAA_ABL(10)
     default: break;
   }
 #undef SAA_ABL

@@ -889,7 +889,7 @@ struct JointState {
   int32_t room_owned[32], room_halo[32];
 };
 
-int32_t joint_pack_list(const uint16_t *items, int32_t n_items, JointState &js, std::vector<uint16_t> &out) {
+int32_t joint_pack_list(const uint16_t *items, int32_t n_items, JointState &js, std::vector<uint16_t> &out, double pad = 0.0) {
   constexpr int kHalf = 32, kSlots = 5, kWindow = 1024;
   out.clear();
   if (n_items <= 0) return 0;
@@ -906,6 +906,7 @@ int32_t joint_pack_list(const uint16_t *items, int32_t n_items, JointState &js, 
     }
   };
   int32_t done = 0, remaining = n_items;
+  int32_t pad_budget = static_cast<int32_t>(pad * n_items);  // idle lanes allowed instead of clashes (reorder_for_lds: `pad`)
   while (remaining > 0) {
     out.resize(8 * static_cast<size_t>(done + kHalf), 0);
     for (int32_t l = 0; l < kHalf; ++l) out[8 * static_cast<size_t>(done + l) + 5] = 2;
@@ -999,6 +1000,10 @@ int32_t joint_pack_list(const uint16_t *items, int32_t n_items, JointState &js, 
       }
     // the rest where it raises the worst multiplicities least (free nodes cost nothing: they take a free bank if any)
     while (placed < kHalf && remaining > 0) {
+      if (pad_budget > 0 && placed > 0) {  // leave the remaining lanes of this half idle instead of clashing
+        pad_budget -= kHalf - placed;
+        break;
+      }
       int32_t best_p = -1, best_q = 0, best_g = 0, best_k = 1 << 30;
       for (int32_t p = 0; p < lim && best_k > 0; ++p) {
         if (pool[p] < 0) continue;
@@ -1691,8 +1696,8 @@ bool build_once(int32_t n_nodes, int32_t n_elems, const double *xyz, const int32
         for (int32_t i = d.n_owned; i < d.n_owned + d.n_halo; ++i) ++js.room_halo[i & 31];
         cand.pio.clear();
         cand.pih.clear();
-        cand.mi = joint_pack_list(out.data(), n_in, js, cand.pa);
-        cand.mb = joint_pack_list(out.data() + 8 * static_cast<size_t>(n_in), ni - n_in, js, cand.pb);
+        cand.mi = joint_pack_list(out.data(), n_in, js, cand.pa, pad);
+        cand.mb = joint_pack_list(out.data() + 8 * static_cast<size_t>(n_in), ni - n_in, js, cand.pb, pad);
         auto colours = [&](int32_t first, int32_t n, int32_t *room, std::vector<int> &col) {
           col.resize(n);
           for (int32_t l = 0; l < n; ++l) {

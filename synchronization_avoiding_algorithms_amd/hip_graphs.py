@@ -15,7 +15,7 @@ reduction - stayed right.
 
 So the package switches packet capture off before the HIP runtime starts (:func:`configure_runtime`, called when the
 package is imported), and every user of a torch-captured graph first asks :func:`replays_are_trustworthy`, which
-captures and replays the known trigger on the device and compares with eager execution; when that canary fails (the switch
+captures the structure that showed the fault, replays it four times and compares with eager execution; when that canary fails (the switch
 came too late because the process had initialised HIP already, or another runtime version misbehaves differently) the
 caller runs eagerly.
 """
@@ -36,7 +36,7 @@ def configure_runtime():
 
 def replays_are_trustworthy(device=None) -> bool:
     """True iff a captured graph holding multi-block reductions replays correctly on ``device`` in THIS process (result
-    cached per device).  Three replays on fresh inputs, each compared bit for bit with eager execution."""
+    cached per device).  Four replays of the known trigger, each compared bit for bit with eager execution."""
     import torch
 
     if not torch.cuda.is_available():
@@ -48,17 +48,24 @@ def replays_are_trustworthy(device=None) -> bool:
     ok = True
     try:
         with torch.no_grad():
+            # the structure that showed the fault (round 2's validation pass without its model): five batches, per batch
+            # three mean-square reductions over 10 x 20 x 1000 values and three in-place additions into fp64 running sums
             gen = torch.Generator(device=dev).manual_seed(11)
-            X = torch.rand(10, 20, 1000, device=dev, generator=gen)
-            Y = torch.rand(10, 20, 1000, device=dev, generator=gen)
-            out = torch.zeros(3, dtype=torch.float64, device=dev)
+            batches = [(torch.rand(b, 20, 1000, device=dev, generator=gen) - 1.0,
+                        torch.rand(b, 20, 1000, device=dev, generator=gen) - 1.0) for b in (10, 10, 10, 10, 1)]
+            sums = torch.zeros(3, dtype=torch.float64, device=dev)
+            mse = torch.nn.functional.mse_loss
 
             def body():
-                loss = torch.nn.functional.mse_loss(X * 0.5 + 0.125, Y)            # multi-block reduction
-                out[0] = loss.double()
-                out[1] = (1.0 - loss / torch.nn.functional.mse_loss(Y, torch.mean(Y) + torch.zeros_like(Y))).double()
-                out[2] = (X.double().sum() - Y.double().sum())
+                sums.zero_()
+                for X, Y in batches:
+                    loss = mse(X * 0.5 + 0.125, Y)
+                    sums[0] += loss.double()
+                    sums[1] += (1.0 - loss / mse(Y, torch.mean(Y) + torch.zeros_like(Y))).double()
+                    sums[2] += (1.0 - loss / mse(Y, torch.zeros_like(Y))).double()
 
+            body()
+            want = sums.clone()
             side = torch.cuda.Stream(device=dev)
             side.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(side):
@@ -67,14 +74,13 @@ def replays_are_trustworthy(device=None) -> bool:
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 body()
-            for _ in range(3):
-                X.copy_(torch.rand(X.shape, device=dev, generator=gen))
-                Y.copy_(torch.rand(Y.shape, device=dev, generator=gen))
+            z = torch.zeros(1000, device=dev)
+            for _ in range(4):  # (the first replay is right either way; the second was wrong in every failing run)
+                for _ in range(20):
+                    z.add_(1.0)
                 graph.replay()
-                got = out.clone()
-                body()
                 torch.cuda.synchronize(dev)
-                ok = ok and bool(torch.equal(got, out))
+                ok = ok and bool(torch.equal(sums, want))
             del graph
     except Exception as exc:  # noqa: BLE001 - a runtime that cannot capture at all is not trustworthy either
         warnings.warn(f"HIP graph canary could not run ({exc!r}): torch-captured graphs stay off")

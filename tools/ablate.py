@@ -27,10 +27,21 @@ lib.saa_debug_time_ablated.restype = C.c_int
 lib.saa_debug_time_ablated.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_double)]
 names = {0: "full", 1: "no LDS atomics", 2: "no indexed LDS reads", 3: "no staging loads",
          4: "no update phase", 5: "no element phase", 6: "element VALU only", 7: "element LDS only",
-         9: "8 steps of blocks, 1 launch"}
+         9: "8 steps of blocks, 1 launch", 10: "element phase only (3 + 4)"}
 print("plan", sol.plan_stats())
 ms = C.c_double()
-for v in (0, 1, 2, 3, 4, 5, 6, 7, 9, 0):
+for v in (0, 1, 2, 3, 4, 5, 6, 7, 9, 10, 0):
     lib.saa_debug_time_ablated(sol._h, v, 200, C.byref(ms))
     lib.saa_debug_time_ablated(sol._h, v, 1000, C.byref(ms))
-    print(f"variant {v} ({names[v]:22s}): {ms.value:8.3f} us/launch")
+    print(f"variant {v:2d} ({names[v]:26s}): {ms.value:8.3f} us/launch")
+# Plans with two workgroups per CU (the 8.2M-tet beam on one GPU): the same variants with room for ONE workgroup per CU
+# only (unused dynamic LDS on top of the image) - what the element phase delivers at 8 waves per CU instead of 16, i.e.
+# what a workgroup whose waves were split into a staging / updating half and a computing half would have to live on.
+st = sol.plan_stats()
+if 2 * st["lds_bytes"] <= 160 * 1024 and st["n_blocks"] > 256:
+    os.environ["SAA_ABLATE_EXTRA_LDS"] = str(160 * 1024 // 2 - st["lds_bytes"] + 2048)
+    for v in (0, 5, 10, 6, 7, 0):
+        lib.saa_debug_time_ablated(sol._h, v, 200, C.byref(ms))
+        lib.saa_debug_time_ablated(sol._h, v, 1000, C.byref(ms))
+        print(f"ONE workgroup per CU, variant {v:2d} ({names[v]:26s}): {ms.value:8.3f} us/launch")
+    os.environ.pop("SAA_ABLATE_EXTRA_LDS")
