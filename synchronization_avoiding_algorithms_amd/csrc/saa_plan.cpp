@@ -347,7 +347,7 @@ int32_t build_items(const std::vector<uint16_t> &loc, int32_t n_elem, int32_t n_
   // and a single costs a lane as much as a pair.  Augmenting paths of length three - single s, its neighbour f matched
   // with g, g's other neighbour t single: (s,f) (g,t) instead of (f,g) - and, in a second sweep, of length five pick most
   // of them up; here an all-owned element may also pair with one that has halo nodes (the item then waits for the halo
-  // records like its second element would have).  Only on request (`augment`: the caller asks when more than 4 % of a
+  // records like its second element would have).  Only on request (`augment`: the caller asks when more than 1.5 % of a
   // block's elements stayed single): on lattices (99.8 % paired) the pairing stays exactly what the pattern classes of
   // the LDS packing were tuned on.
   if (augment && n_single > 0) {
@@ -359,57 +359,46 @@ int32_t build_items(const std::vector<uint16_t> &loc, int32_t n_elem, int32_t n_
       apex_first(f, nbk[4 * static_cast<size_t>(e) + k], B);
       return compatible(A, B) ? f : -1;
     };
-    // a free (single) neighbour of g other than `avoid`, or -1
-    auto free_neighbour = [&](int32_t g, int32_t avoid, int &kk_out) -> int32_t {
-      for (int kk = 0; kk < 4; ++kk) {
-        const int32_t t = eligible(g, kk);
-        if (t < 0 || t == avoid || mate[t] >= 0) continue;
-        kk_out = kk;
-        return t;
+    // augmenting paths by depth-first search (the bipartite scheme on a general graph: an element enters a path at most
+    // once, so odd cycles are not contracted and a few paths are missed, but every path found is a valid one); paths of
+    // up to kDepth exchanges, shortest first
+    std::vector<int32_t> seen(n_elem, -1);
+    int32_t stamp = 0;
+    constexpr int kDepth = 10;
+    // u is free (or has just lost its partner): find it a partner, displacing others along the way
+    auto grow = [&](auto &&self, int32_t u, int depth) -> bool {
+      for (int k = 0; k < 4; ++k) {  // a free neighbour first
+        const int32_t v = eligible(u, k);
+        if (v < 0 || seen[v] == stamp || mate[v] >= 0) continue;
+        seen[v] = stamp;
+        join(u, k);
+        return true;
       }
-      return -1;
+      if (depth == 0) return false;
+      for (int k = 0; k < 4; ++k) {
+        const int32_t v = eligible(u, k);
+        if (v < 0 || seen[v] == stamp) continue;
+        const int32_t w = mate[v];
+        if (w < 0 || seen[w] == stamp) continue;
+        seen[v] = seen[w] = stamp;
+        mate[w] = -1;  // w gives v up if it finds another partner
+        if (self(self, w, depth - 1)) {
+          join(u, k);
+          return true;
+        }
+        mate[w] = v;   // (mface[w] is untouched: the pair stands as it was)
+      }
+      return false;
     };
-    for (int sweep = 0; sweep < 3; ++sweep) {
+    for (int depth = 1; depth <= kDepth; ++depth) {
       int32_t gained = 0;
       for (int32_t s0 : order) {
         if (mate[s0] >= 0) continue;
-        bool done = false;
-        for (int k = 0; k < 4 && !done; ++k) {
-          const int32_t f = eligible(s0, k);
-          if (f < 0) continue;
-          if (mate[f] < 0) {  // two singles side by side (left by an earlier exchange)
-            join(s0, k);
-            done = true;
-            break;
-          }
-          const int32_t g = mate[f];
-          int kk = -1;
-          const int32_t t = free_neighbour(g, s0, kk);
-          if (t >= 0) {  // length three
-            join(s0, k);
-            join(g, kk);
-            done = true;
-            break;
-          }
-          if (sweep == 0) continue;
-          // length five: g's other neighbours u, matched with v, and v has a free neighbour w
-          for (int k2 = 0; k2 < 4 && !done; ++k2) {
-            const int32_t u = eligible(g, k2);
-            if (u < 0 || u == f || mate[u] < 0) continue;
-            const int32_t v = mate[u];
-            if (v == s0 || v == f || v == g) continue;
-            int k3 = -1;
-            const int32_t w = free_neighbour(v, s0, k3);
-            if (w < 0 || w == g || w == f || w == u) continue;
-            join(s0, k);
-            join(g, k2);
-            join(v, k3);
-            done = true;
-          }
-        }
-        gained += done;
+        ++stamp;
+        seen[s0] = stamp;
+        gained += grow(grow, s0, depth);
       }
-      if (gained == 0) break;
+      if (gained == 0 && depth >= 3) break;
     }
   }
   std::vector<char> out_done(n_elem, 0);
@@ -1588,9 +1577,9 @@ bool build_once(int32_t n_nodes, int32_t n_elems, const double *xyz, const int32
           ni = ni_s;
           spatial = true;
         }
-        // an unstructured mesh (more than 4 % of the block's elements single either way): the same matching improved by
-        // augmenting paths
-        if (200 * static_cast<int64_t>(ni) > 104 * static_cast<int64_t>(ne)) {
+        // an unstructured mesh (more than 1.5 % of the block's elements single either way; lattices: 0.2 %): the same
+        // matching improved by augmenting paths
+        if (2000 * static_cast<int64_t>(ni) > 1015 * static_cast<int64_t>(ne)) {
           const int32_t ni_a = spatial ? build_items(loc_b, ne, d.n_owned, items_s, xl.data(), h_mesh, true)
                                        : build_items(loc_b, ne, d.n_owned, items_s, nullptr, 0.0, true);
           if (ni_a < ni) {
