@@ -930,7 +930,14 @@ def single_gpu_legs(args, legs, put, sol, stats, n, ne_total, nn_total, device):
         roof["frac_of_measured_copy"] = achieved / copy_bw
         return roof
 
-    run("roofline", 10.0, roofline, "roofline")
+    shared = {}
+
+    def roofline_and_keep():
+        roof = roofline()
+        shared["structured_us"] = roof["us_per_step"]
+        return roof
+
+    run("roofline", 10.0, roofline_and_keep, "roofline")
     sol.close()
     mesh38 = {}
 
@@ -946,7 +953,14 @@ def single_gpu_legs(args, legs, put, sol, stats, n, ne_total, nn_total, device):
         run("per_gpu_of_8", 75.0, lambda: per_gpu_of_8_leg(get38(), device, args.min_timed_ms), "per_gpu_of_8")
         run("cache_exceeding", 110.0, lambda: cache_exceeding_leg(get38(), device, args.min_timed_ms), "cache_exceeding")
         mesh38.clear()
-        run("unstructured", 120.0, lambda: unstructured_leg(n, device, args.min_timed_ms), "unstructured")
+
+        def unstructured():
+            leg = unstructured_leg(n, device, args.min_timed_ms)
+            if "structured_us" in shared:  # same run, same box, same kind of timing (HIP events over >= 1 s)
+                leg["step_time_over_structured"] = 1e3 * leg["ms_per_step"] / shared["structured_us"]
+            return leg
+
+        run("unstructured", 120.0, unstructured, "unstructured")
     else:
         for leg in ("per_gpu_of_8", "cache_exceeding", "unstructured"):
             legs.skip(leg, "only with the default mesh (--mesh structured, no --refine)")

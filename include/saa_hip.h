@@ -245,6 +245,9 @@ int saa_set_resident_kernel(saa_solver *s, int32_t enable);
 /* Run-time options of a handle, by name (the library itself reads no environment variable):
  *   "synced_graph"    1 (default) / 0: saa_step_synced replays HIP graphs of three steps each / enqueues every kernel and
  *                     collective itself (the role of the per-step MPI calls of Distributed_tools.py:77-92);
+ *   "split_stepping"  1 (default) / 0: partitions too large for the resident kernel (several rounds of workgroups per
+ *                     launch) step their blocks as three sets on three streams, so that one set's launch boundaries hide
+ *                     under another's work / one launch of all blocks per step;
  *   "wait_timeout_s"  bound, in seconds (default 30), of every in-kernel wait for another workgroup or rank (resident
  *                     kernel, peer exchange); a wait that gives up is reported as SAA_E_STATE by saa_synchronize.
  * The reference has no counterpart (an MPI rank that loses its peer hangs, Distributed_tools.py:77-92). */

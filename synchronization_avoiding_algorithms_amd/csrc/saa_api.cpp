@@ -10,6 +10,7 @@
 #include <cstring>
 #include <mutex>
 #include <new>
+#include <numeric>
 #include <string>
 #include <utility>
 #include <vector>
@@ -169,6 +170,13 @@ struct saa_solver {
   saa::PeerMap peer{};
   bool peer_ready = false;
   unsigned peer_seq = 0;
+  // Split stepping (plans of several rounds of workgroups, i.e. partitions beyond the resident kernel's capacity): the
+  // blocks in three sets - left, right and the blocks between them - stepped on three streams, setup_split_stepping()
+  DevBuf<saa::BlockDesc> split_blocks[3];
+  int32_t split_n[3] = {0, 0, 0};
+  hipStream_t split_stream[3] = {nullptr, nullptr, nullptr};
+  hipEvent_t split_ev[3] = {nullptr, nullptr, nullptr}, split_fork = nullptr;
+  bool split_ok = false, split_wanted = true;
 
   void rotate() {
     const int old_n = in_;
@@ -202,6 +210,16 @@ struct saa_solver {
     peer_mem = nullptr;
     px_blk_off.release(); px_node.release(); px_sidx.release(); px_nb_off.release(); px_err.release();
     px_dst.release(); px_pstride.release(); px_recv.release(); px_push_rec.release(); px_recv_rec.release(); px_second_rec.release(); px_map.release(); px_holders.release(); px_own.release(); px_test.release();
+    for (int j = 0; j < 3; ++j) {
+      split_blocks[j].release();
+      if (split_stream[j]) (void)hipStreamDestroy(split_stream[j]);
+      if (split_ev[j]) (void)hipEventDestroy(split_ev[j]);
+      split_stream[j] = nullptr;
+      split_ev[j] = nullptr;
+    }
+    if (split_fork) (void)hipEventDestroy(split_fork);
+    split_fork = nullptr;
+    split_ok = false;
   }
 };
 
@@ -555,6 +573,130 @@ void launch_force(saa_solver *s, const double *d, double *f) {
     saa::launch_force_only(s->mesh, s->threads, s->lds_bytes, s->stream, d, f);
 }
 
+int check_launch();
+
+// Split stepping.  A partition too large for the resident kernel runs one launch of the fused kernel per step, several
+// rounds of workgroups each (8.2M tets on one GPU: 2048 blocks on 512 slots), and every launch boundary costs its tail -
+// CUs idling while the last workgroups finish - and its ramp - all workgroups staging at once: eight steps' worth of
+// blocks in ONE launch take 68.5 us per step against 75.9 (profiles/r04_fused_8Mtets_ablation.txt, variant 9).  A step
+// only needs its NEIGHBOUR blocks' previous step, though.  So the blocks are split along the longest axis of the mesh into
+// a left set L, a right set R and the set M of blocks whose halo reaches across the cut: L's halo nodes are owned by L or
+// M, R's by R or M.  With X_s = "step s of the blocks of X":  L_s needs L_(s-1), M_(s-1);  R_s needs R_(s-1), M_(s-1);
+// M_s needs all three of step s-1.  L, R and M run on a stream each, tied by events exactly so; L and R (half of the
+// work each: the chain L_(s+1) <- M_s <- R_(s-1) makes the smaller of two unequal halves wait) fill each other's tails
+// and ramps, because nothing but M ties their phases together.  Write-after-read on the three
+// rotating state buffers: X_s overwrites d^(s-2) of its own nodes, last read as d^(n-1) by X_(s-1) (same stream) and as a
+// halo value by step s-2 of a neighbour set, which the event chain has behind it.  Same kernel, same arithmetic per
+// block: results do not depend on the split.
+void setup_split_stepping(saa_solver *s, const double *xyz_caller) {
+  s->split_ok = false;
+  const saa::Plan &plan = s->plan;
+  const int32_t nb = static_cast<int32_t>(plan.blocks.size());
+  int cus = 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, s->device) != hipSuccess || cus <= 0) {
+    (void)hipGetLastError();
+    return;
+  }
+  if (nb < 4 * cus) return;  // (plans of a round or two of workgroups: nothing to hide; a resident-capable plan of that
+                             //  many blocks gets here only when the resident kernel is switched off, saa_step)
+  // centroid of every block along the longest axis of the mesh
+  double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+  for (int32_t i = 0; i < plan.n_nodes; ++i)
+    for (int k = 0; k < 3; ++k) {
+      lo[k] = std::min(lo[k], xyz_caller[3 * static_cast<size_t>(i) + k]);
+      hi[k] = std::max(hi[k], xyz_caller[3 * static_cast<size_t>(i) + k]);
+    }
+  int ax = 0;
+  for (int k = 1; k < 3; ++k)
+    if (hi[k] - lo[k] > hi[ax] - lo[ax]) ax = k;
+  std::vector<double> cen(nb, 0.0);
+  std::vector<int32_t> start(nb);
+  for (int32_t b = 0; b < nb; ++b) {
+    const saa::BlockDesc &d = plan.blocks[b];
+    start[b] = d.node_start;
+    for (int32_t l = 0; l < d.n_owned; ++l)
+      cen[b] += xyz_caller[3 * static_cast<size_t>(plan.new_to_old[d.node_start + l]) + ax];
+    cen[b] /= std::max(d.n_owned, 1);
+  }
+  std::vector<int32_t> order(nb);
+  std::iota(order.begin(), order.end(), 0);
+  std::sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return cen[a] < cen[b] || (cen[a] == cen[b] && a < b); });
+  int64_t work = 0, acc = 0;
+  for (const auto &d : plan.blocks) work += d.n_elem;
+  std::vector<int8_t> side(nb, 1);  // 0 = left, 1 = right
+  int left_pct = 50;  // (measured: 30 % no gain, 40 % 71.3, 45 % 69.8, 50 % 68.1 us per step at 8.2M tets against 75.4 unsplit)
+  if (const char *env = saa::diag_env("SAA_SPLIT_LEFT_PCT")) left_pct = std::min(90, std::max(10, std::atoi(env)));
+  for (int32_t b : order) {
+    if (100 * acc >= static_cast<int64_t>(left_pct) * work) break;
+    side[b] = 0;
+    acc += plan.blocks[b].n_elem;
+  }
+  std::vector<int8_t> set(side);  // 0 = L, 2 = R (from side 1), 1 = M
+  for (auto &v : set) v = v ? 2 : 0;
+  for (int32_t b = 0; b < nb; ++b) {
+    const saa::BlockDesc &d = plan.blocks[b];
+    for (int32_t h = 0; h < d.n_halo; ++h) {
+      const int32_t g = plan.halo_ids[d.halo_off + h];
+      const int32_t owner = static_cast<int32_t>(std::upper_bound(start.begin(), start.end(), g) - start.begin()) - 1;
+      if (side[owner] != side[b]) {
+        set[b] = 1;
+        break;
+      }
+    }
+  }
+  std::vector<saa::BlockDesc> lists[3];
+  for (int32_t b = 0; b < nb; ++b) lists[set[b]].push_back(plan.blocks[b]);
+  if (lists[0].size() < static_cast<size_t>(cus) || lists[2].size() < static_cast<size_t>(cus) || lists[1].empty()) return;
+  for (int j = 0; j < 3; ++j) {
+    s->split_n[j] = static_cast<int32_t>(lists[j].size());
+    if (s->split_blocks[j].upload(lists[j]) != hipSuccess || hipStreamCreateWithFlags(&s->split_stream[j], hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&s->split_ev[j], hipEventDisableTiming) != hipSuccess) {
+      (void)hipGetLastError();
+      return;  // (what was created is released with the handle)
+    }
+  }
+  if (hipEventCreateWithFlags(&s->split_fork, hipEventDisableTiming) != hipSuccess) {
+    (void)hipGetLastError();
+    return;
+  }
+  s->split_ok = true;
+}
+
+// `nsteps` exchange-free steps of the fused kernel through the three streams; the caller's stream is forked at the start
+// and joined at the end, so the call is ordered like any other on it.
+int split_steps(saa_solver *s, int32_t nsteps) {
+  HIP_TRY(hipEventRecord(s->split_fork, s->stream));
+  for (int j = 0; j < 3; ++j) HIP_TRY(hipStreamWaitEvent(s->split_stream[j], s->split_fork, 0));
+  saa::DeviceMesh m[3] = {s->mesh, s->mesh, s->mesh};
+  for (int j = 0; j < 3; ++j) {
+    m[j].blocks = s->split_blocks[j].p;
+    m[j].n_blocks = s->split_n[j];
+  }
+  hipStream_t sl = s->split_stream[0], sm = s->split_stream[1], sr = s->split_stream[2];
+  hipEvent_t el = s->split_ev[0], em = s->split_ev[1], er = s->split_ev[2];
+  for (int32_t k = 0; k < nsteps; ++k) {
+    s->set_ramp();
+    const double *d0 = s->dbuf[s->i0].p, *dn = s->dbuf[s->in_].p;
+    double *d1 = s->dbuf[s->i1].p;
+    if (k > 0) {  // (the events still hold the records of step k - 1)
+      HIP_TRY(hipStreamWaitEvent(sm, el, 0));
+      HIP_TRY(hipStreamWaitEvent(sm, er, 0));
+      HIP_TRY(hipStreamWaitEvent(sl, em, 0));
+      HIP_TRY(hipStreamWaitEvent(sr, em, 0));
+    }
+    saa::launch_fused_step(m[1], s->threads, s->lds_bytes, sm, d0, dn, d1, nullptr, nullptr, nullptr, s->consts);
+    saa::launch_fused_step(m[0], s->threads, s->lds_bytes, sl, d0, dn, d1, nullptr, nullptr, nullptr, s->consts);
+    saa::launch_fused_step(m[2], s->threads, s->lds_bytes, sr, d0, dn, d1, nullptr, nullptr, nullptr, s->consts);
+    HIP_TRY(hipEventRecord(em, sm));
+    HIP_TRY(hipEventRecord(el, sl));
+    HIP_TRY(hipEventRecord(er, sr));
+    s->rotate();
+    s->tn = s->tn + s->consts.dt;  // Data_prepare.py:235
+  }
+  for (int j = 0; j < 3; ++j) HIP_TRY(hipStreamWaitEvent(s->stream, s->split_ev[j], 0));
+  return check_launch();
+}
+
 // Synchronised steps (fused kernel -> ncclAllReduce -> finish kernel) as replayed HIP graphs: three launches per step
 // and a collective's enqueue cost make the RCCL transport launch-bound from the host.  One graph holds THREE steps - after
 // three the rotating state buffers are back where they were, so the captured pointers stay right - and there is one graph
@@ -863,6 +1005,7 @@ int saa_create(const saa_problem *pb, saa_solver **out) {
   s->consts.half_alpha = 0.5 * pb->alpha;
   s->tn = 0.0;
   setup_persistent(s);
+  setup_split_stepping(s, pb->xyz);
   *out = s;
   return SAA_OK;
 }
@@ -980,6 +1123,7 @@ int saa_step(saa_solver *s, int32_t nsteps) {
   HIP_TRY(hipSetDevice(s->device));
   int32_t k0 = 0;
   if (int rc = try_persistent_steps(s, nsteps, nullptr, 0, nullptr, 0, &k0)) return rc;
+  if (k0 == 0 && s->split_ok && s->split_wanted && !s->det && !s->rec_traj && nsteps >= 4) return split_steps(s, nsteps);
   for (int32_t k = k0; k < nsteps; ++k) {
     s->set_ramp();
     launch_step(s, nullptr, nullptr, nullptr);
@@ -1481,6 +1625,10 @@ int saa_set_option(saa_solver *s, const char *name, double value) {
     s->sync_graph_wanted = value != 0.0;
     return SAA_OK;
   }
+  if (key == "split_stepping") {
+    s->split_wanted = value != 0.0;
+    return SAA_OK;
+  }
   if (key == "wait_timeout_s") {
     if (!(value > 0.0) || value > 3600.0) return fail(SAA_E_ARG, "saa_set_option: wait_timeout_s must be in (0, 3600]");
     s->wait_timeout_s = std::max(1e-7, value);
@@ -1492,7 +1640,7 @@ int saa_set_option(saa_solver *s, const char *name, double value) {
     }
     return SAA_OK;
   }
-  return fail(SAA_E_ARG, "saa_set_option: unknown option '" + key + "' (synced_graph, wait_timeout_s)");
+  return fail(SAA_E_ARG, "saa_set_option: unknown option '" + key + "' (synced_graph, split_stepping, wait_timeout_s)");
 }
 
 int saa_set_resident_kernel(saa_solver *s, int32_t enable) {

@@ -439,6 +439,44 @@ def test_resident_grid_sizing_several_blocks_per_cu_and_oversized_grids(tmp_path
     assert r.returncode == 0, r.stderr[-3000:]
 
 
+def test_split_stepping_of_a_multi_round_plan_equals_one_launch_per_step_and_the_oracle():
+    """Partitions beyond the resident kernel's capacity run the fused kernel, several rounds of workgroups per step; their
+    blocks are then stepped as three sets (left, between, right) on three streams tied by events, so that one set's launch
+    boundaries hide under another's work (saa_api.cpp: split_steps).  Same kernel per block, other schedule: the result
+    must be the oracle's, and the plain schedule's up to the order of the LDS atomics."""
+    fo = _oracle()
+    from synchronization_avoiding_algorithms_amd.mesh import structured_beam
+
+    mesh = structured_beam(8)
+    sol, lay, dt, lumped, fpre = _serial_solver(mesh, block_nodes=12, threads=64)
+    st = sol.plan_stats()
+    sol.set_resident_kernel(False)  # (blocks this small would all fit the chip at once: the fused kernel is what is under test)
+    assert st["n_blocks"] >= 1024 and not sol.resident_kernel_info()["capable"], st   # four rounds and more on 256 CUs
+    ranks, odt, _, _ = fo.setup_problem(mesh.points, mesh.tets, mesh.triangles, 1, np.zeros(len(mesh.tets), dtype=int))
+    rp = ranks[0]
+    assert odt == dt
+    rng = np.random.default_rng(8)
+    d0 = rng.uniform(-1e-4, 1e-4, size=(sol.n_dof, 1))
+    dn = d0 + rng.uniform(-1e-6, 1e-6, size=(sol.n_dof, 1))
+    d0[rp.dirichlet] = 0
+    dn[rp.dirichlet] = 0
+    tn, o0, on = 0.25, d0, dn
+    for _ in range(61):
+        o1 = fo.explicit_step(rp.K, rp.F, rp.dirichlet, tn, dt, o0, on, rp.l_M, 0.5)
+        on, o0, tn = o0, o1, tn + dt
+    got = {}
+    for split in (1, 0):
+        sol.set_option("split_stepping", split)
+        sol.set_state(d0, dn, 0.25)
+        for k in (40, 3, 18):   # (calls of fewer than four steps take the plain schedule: the two must mix)
+            sol.step(k)
+        g0, gn, gt = sol.get_state()
+        assert gt == tn and rel_l2(g0, o0) < 1e-11 and rel_l2(gn, on) < 1e-11, split
+        got[split] = g0
+    assert rel_l2(got[1], got[0]) < 1e-12
+    sol.close()
+
+
 def test_two_handles_step_resident_on_two_streams_at_once():
     """Two solvers in one process, each with its own stream, each with a resident grid that fills the chip (256 workgroups
     of the 1M-tet beam): their resident launches must not overlap - each would hold a part of the CUs and wait for the
