@@ -779,13 +779,24 @@ def unstructured_leg(n, device, min_ms):
     stats = sol.plan_stats()
     sol.synchronize()
     sol.close()
-    return {"workload": f"Delaunay triangulation of {nn} random points in the 25 x 1 x 1 box (boundary points on a grid of "
-                        f"the mean spacing): {ne} tets, one partition, fp64, dt={dt:.6e}",
-            "kernel": "persistent_steps_kernel<false,false>" if res["capable"] else "fused_step_kernel<false>",
-            "ms_per_step": 1e3 * s_step, "steps_timed": n_steps, "element_updates_per_s": ne / s_step,
-            "roofline": contract_roofline(ne, nn, s_step), "lds_conflict_factor": stats["lds_conflict_factor"],
-            "lds_atomic_conflict_factor": stats["lds_atomic_conflict_factor"], "plan": stats,
-            "mesh_seconds": mesh_s, "setup_seconds": setup_s}
+    out = {"workload": f"Delaunay triangulation of {nn} random points in the 25 x 1 x 1 box (boundary points on a grid of "
+                       f"the mean spacing): {ne} tets, one partition, fp64, dt={dt:.6e}",
+           "kernel": "persistent_steps_kernel<false,false>" if res["capable"] else "fused_step_kernel<false>",
+           "ms_per_step": 1e3 * s_step, "steps_timed": n_steps, "element_updates_per_s": ne / s_step,
+           "roofline": contract_roofline(ne, nn, s_step), "lds_conflict_factor": stats["lds_conflict_factor"],
+           "lds_atomic_conflict_factor": stats["lds_atomic_conflict_factor"], "plan": stats,
+           "mesh_seconds": mesh_s, "setup_seconds": setup_s}
+    traffic, onchip, src, note = committed_counters(("resident" if res["capable"] else "fused") + f"{n}_delaunay", stats)
+    if traffic is not None:  # (per launch of `spl` steps, like the headline's)
+        out["roofline"].update(traffic=traffic, traffic_source=src,
+                               hbm_measured={"GBps": traffic / (s_step * spl) / 1e9, "frac_of_peak": traffic / (s_step * spl) / HBM_PEAK,
+                                             "traffic_over_algorithmic": traffic / (spl * out["roofline"]["algorithmic_bytes_per_step"])})
+    if onchip is not None:
+        out["roofline"]["onchip"] = {k: onchip[k] for k in ("valu_busy", "lds_busy", "lds_bank_conflict_share",
+                                                          "wave_wait_share", "wave_issue_stall_share") if k in onchip}
+    if note:
+        out["roofline"]["counters_note"] = note
+    return out
 
 
 def launch_ranks(args):
