@@ -597,8 +597,11 @@ void setup_split_stepping(saa_solver *s, const double *xyz_caller) {
     (void)hipGetLastError();
     return;
   }
-  if (nb < 4 * cus) return;  // (plans of a round or two of workgroups: nothing to hide; a resident-capable plan of that
-                             //  many blocks gets here only when the resident kernel is switched off, saa_step)
+  // Measured (tools/split_ab.py, 512-thread workgroups, 512 slots): 1024 blocks = two rounds lose 15 % (41.1 -> 47.5 us),
+  // 1536 = three rounds are neutral (57.3), 2048 = four rounds gain 9.5 % (75.3 -> 68.1), 3328 = 6.5 rounds gain 4.4 %
+  // (132.7 -> 126.9): from four rounds on.  (A resident-capable plan of that many blocks gets here only when the resident
+  // kernel is switched off, saa_step.)
+  if (nb < 8 * cus) return;
   // centroid of every block along the longest axis of the mesh
   double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
   for (int32_t i = 0; i < plan.n_nodes; ++i)

@@ -448,10 +448,10 @@ def test_split_stepping_of_a_multi_round_plan_equals_one_launch_per_step_and_the
     from synchronization_avoiding_algorithms_amd.mesh import structured_beam
 
     mesh = structured_beam(8)
-    sol, lay, dt, lumped, fpre = _serial_solver(mesh, block_nodes=12, threads=64)
+    sol, lay, dt, lumped, fpre = _serial_solver(mesh, block_nodes=6, threads=64)
     st = sol.plan_stats()
     sol.set_resident_kernel(False)  # (blocks this small would all fit the chip at once: the fused kernel is what is under test)
-    assert st["n_blocks"] >= 1024 and not sol.resident_kernel_info()["capable"], st   # four rounds and more on 256 CUs
+    assert st["n_blocks"] >= 2048 and not sol.resident_kernel_info()["capable"], st   # the size from which the split is used
     ranks, odt, _, _ = fo.setup_problem(mesh.points, mesh.tets, mesh.triangles, 1, np.zeros(len(mesh.tets), dtype=int))
     rp = ranks[0]
     assert odt == dt
