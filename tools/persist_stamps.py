@@ -22,7 +22,7 @@ parts = int(pos[1]) if len(pos) > 1 else 1
 prank = int(pos[2]) if len(pos) > 2 else 0
 peer = len(pos) > 3 and pos[3] == "peer"
 steps = 1000
-mesh = bench_mesh(n, "jittered") if "--mesh=jittered" in sys.argv else structured_beam(n)
+mesh = bench_mesh(n, "jittered") if "--mesh=jittered" in sys.argv else (bench_mesh(n, "delaunay") if "--mesh=delaunay" in sys.argv else structured_beam(n))
 sol, lay, _, _ = build_rank_solver(mesh, parts, prank, 0)
 st = sol.plan_stats()
 waves = st["n_blocks"] * st["threads"] // 64
