@@ -63,3 +63,23 @@ def test_job_start_time_ignores_shells_and_test_runners():
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60,
                        env=dict(os.environ, SAA_BENCH_T0=repr(time.time() - 100)))
     assert 99 < float(r.stdout) < 130
+
+
+def test_committed_counters_are_only_handed_out_for_the_profiled_plan():
+    """roofline.traffic / onchip come from committed PMC passes of ANOTHER run of the same command: bench.py prints them only
+    while the plan statistics of this run equal the ones recorded with the counters, and says why otherwise."""
+    import importlib
+
+    sys.argv = ["bench.py"]
+    sys.path.insert(0, REPO)
+    bench = importlib.import_module("bench")
+    with open(os.path.join(REPO, "profiles", "r04_pmc_summary.json")) as fh:
+        rec = json.load(fh)["r04_resident19:plan"]
+    stats = {k: rec[k] for k in bench.PLAN_IDENTITY}
+    traffic, onchip, src, note = bench.committed_counters("resident19", stats)
+    assert traffic > 1e9 and onchip is not None and "r04_pmc_summary.json" in src
+    assert 0.5 < onchip["valu_busy"] < 1.0 and 0.5 < onchip["lds_busy"] < 1.0
+    other = dict(stats, n_items=stats["n_items"] + 1)  # any other plan: refused, with the difference named
+    traffic, onchip, src, note = bench.committed_counters("resident19", other)
+    assert traffic is None and onchip is None and "n_items" in note and "profile again" in note
+    assert bench.committed_counters("resident7", stats) == (None, None, None, None)  # a mesh that was never profiled
