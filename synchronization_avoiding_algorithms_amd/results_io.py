@@ -2,8 +2,9 @@
 
 The reference stores trajectories as HDF5 datasets ``Displacement`` of shape ``(n_dof_local, n_saved)``
 (``Data_prepare.py:243-246``, ``Shared_extraction.py:38-40``, ``Online_predictor.py:321-324``).  ``h5py`` is
-used when importable; otherwise the same array goes to ``<name>.npz`` under the same key, and readers
-accept either."""
+used when importable; else the HDF5 C library itself through ctypes (:mod:`hdf5_c`: the same container, chunked and
+deflated the way ``h5py`` does it for ``compression='gzip'``); only where neither exists does the same array go to
+``<name>.npz`` under the same key.  Readers accept whatever is there."""
 from __future__ import annotations
 
 import os
@@ -30,6 +31,10 @@ def save_displacement(path_hdf5: str, data: np.ndarray, compress: bool = True) -
         with h5.File(path_hdf5, "w") as f:
             f.create_dataset(DATASET, data=data, compression="gzip" if compress else None)
         return path_hdf5
+    from . import hdf5_c
+
+    if hdf5_c.available():
+        return hdf5_c.write_dataset(path_hdf5, DATASET, data, gzip=compress)
     alt = os.path.splitext(path_hdf5)[0] + ".npz"
     (np.savez_compressed if compress else np.savez)(alt, **{DATASET: data})
     return alt
@@ -40,11 +45,16 @@ def load_displacement(path_hdf5: str) -> np.ndarray:
     if os.path.exists(path_hdf5) and h5 is not None:
         with h5.File(path_hdf5, "r") as f:
             return np.array(f[DATASET])
+    if os.path.exists(path_hdf5):
+        from . import hdf5_c
+
+        if hdf5_c.available():
+            return hdf5_c.read_dataset(path_hdf5, DATASET)
     alt = os.path.splitext(path_hdf5)[0] + ".npz"
     if os.path.exists(alt):
         with np.load(alt, allow_pickle=False) as z:
             return z[DATASET]
-    raise FileNotFoundError(f"neither {path_hdf5} (needs h5py) nor {alt} exists")
+    raise FileNotFoundError(f"neither {path_hdf5} (needs h5py or libhdf5) nor {alt} exists")
 
 
 def save_int_list(path: str, values) -> None:
