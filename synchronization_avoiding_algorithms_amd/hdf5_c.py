@@ -6,7 +6,9 @@ data=d1_save, compression='gzip')``; ``Shared_extraction.py:38-40`` without comp
 installed (this image: HDF5 1.10 under ``/opt/conda/lib``, no ``h5py``) the same files are written and read by calling
 it directly: a 2-D little-endian float64 dataset, and for ``compression='gzip'`` what ``h5py`` does with that argument -
 chunked layout with its automatic chunk shape (``h5py/_hl/filters.py: guess_chunk``, restated below) and the deflate
-filter at level 4.  Files written here open in ``h5py`` and vice versa (same container format, same library).
+filter at level 4, fill time "alloc".  Pinned against files ``h5py`` 3.3 itself wrote (``tests/golden/make_golden_hdf5.py``,
+run with the image's Anaconda interpreter, which has it): byte for byte equal except the four bytes of the modification
+time stamp.
 """
 from __future__ import annotations
 
@@ -68,6 +70,7 @@ def load():
         "H5Fclose": (C.c_int, [_hid]), "H5Screate_simple": (_hid, [C.c_int, C.POINTER(_hsize), C.POINTER(_hsize)]),
         "H5Sclose": (C.c_int, [_hid]), "H5Pcreate": (_hid, [_hid]), "H5Pclose": (C.c_int, [_hid]),
         "H5Pset_chunk": (C.c_int, [_hid, C.c_int, C.POINTER(_hsize)]), "H5Pset_deflate": (C.c_int, [_hid, C.c_uint]),
+        "H5Pset_fill_time": (C.c_int, [_hid, C.c_int]),
         "H5Dcreate2": (_hid, [_hid, C.c_char_p, _hid, _hid, _hid, _hid, _hid]), "H5Dopen2": (_hid, [_hid, C.c_char_p, _hid]),
         "H5Dwrite": (C.c_int, [_hid, _hid, _hid, _hid, _hid, C.c_void_p]),
         "H5Dread": (C.c_int, [_hid, _hid, _hid, _hid, _hid, C.c_void_p]), "H5Dclose": (C.c_int, [_hid]),
@@ -81,6 +84,16 @@ def load():
     lib.H5Eset_auto2(0, None, None)  # no error stack on stderr: failures become Python exceptions below
     _lib = lib
     return lib
+
+
+def library_version():
+    """(major, minor, release) of the HDF5 library in use, or None."""
+    lib = load()
+    if lib is None:
+        return None
+    maj, mnr, rel = C.c_uint(), C.c_uint(), C.c_uint()
+    lib.H5get_libversion(C.byref(maj), C.byref(mnr), C.byref(rel))
+    return maj.value, mnr.value, rel.value
 
 
 def _const(lib, name):
@@ -125,8 +138,9 @@ def write_dataset(path, name, data, gzip=True, level=4):
             if lib.H5Zfilter_avail(H5Z_FILTER_DEFLATE) <= 0:
                 raise RuntimeError("this libhdf5 has no deflate filter")
             ch = (_hsize * a.ndim)(*guess_chunk(a.shape, 8))
-            if lib.H5Pset_chunk(pid, a.ndim, ch) < 0 or lib.H5Pset_deflate(pid, int(level)) < 0:
-                raise OSError("H5Pset_chunk / H5Pset_deflate failed")
+            # (h5py also asks for the fill value to be written when a chunk is allocated: H5D_FILL_TIME_ALLOC = 0)
+            if lib.H5Pset_chunk(pid, a.ndim, ch) < 0 or lib.H5Pset_deflate(pid, int(level)) < 0 or lib.H5Pset_fill_time(pid, 0) < 0:
+                raise OSError("H5Pset_chunk / H5Pset_deflate / H5Pset_fill_time failed")
         did = lib.H5Dcreate2(fid, name.encode(), _const(lib, "H5T_IEEE_F64LE_g"), sid, H5P_DEFAULT, pid, H5P_DEFAULT)
         if did < 0:
             raise OSError(f"H5Dcreate2 failed for {name}")
