@@ -636,6 +636,12 @@ def cache_exceeding_leg(mesh38, device, min_ms):
     n = int(min(max(200, np.ceil(min_ms / max(est, 1e-6))), 200000))
     ms = sol.time_steps(n)
     s_step = ms * 1e-3 / n
+    # the same steps with ONE launch of all blocks per step (what rounds 1-3 measured): plans of four rounds of workgroups
+    # and more step their blocks as three sets on three streams by default (saa_set_option("split_stepping"))
+    sol.set_option("split_stepping", 0)
+    sol.time_steps(200)
+    plain_ms = sol.time_steps(max(n // 3, 200)) / max(n // 3, 200)
+    sol.set_option("split_stepping", 1)
     stats = sol.plan_stats()
     sol.synchronize()
     sol.close()
@@ -643,7 +649,11 @@ def cache_exceeding_leg(mesh38, device, min_ms):
     out = {"workload": f"synthetic 25n x n x n Kuhn-tet beam: {ne} tets, {nn} nodes, ONE partition on one GPU, fp64, dt={dt:.6e}",
            "kernel": "persistent_steps_kernel<false,false>" if res["capable"] else "fused_step_kernel<false> (one launch per step)",
            "ms_per_step": 1e3 * s_step, "steps_timed": n, "element_updates_per_s": ne / s_step,
-           "short_region": {"ms_per_step": short, "steps": short_steps}, "setup_seconds": setup_s, "plan": stats}
+           "short_region": {"ms_per_step": short, "steps": short_steps},
+           "schedule": ("split stepping: the blocks as left / middle / right sets on three streams tied by events, launch "
+                        "boundaries hidden under the other sets' work" if stats["n_blocks"] >= 2048 and not res["capable"]
+                        else "one launch of all blocks per step"),
+           "one_launch_per_step_ms": plain_ms, "setup_seconds": setup_s, "plan": stats}
     out["roofline"] = contract_roofline(ne, nn, s_step)
     traffic, onchip, src, note = committed_counters(key, stats)
     if traffic is not None:
