@@ -1,4 +1,4 @@
-"""Not a pytest file: a longer full-size parity run for profiles/ (python tests/long_parity_fullsize.py [steps]).
+"""Not a pytest file: a longer full-size parity run for profiles/ (python tests/long_parity_fullsize.py [steps] [delaunay]).
 
 The 1 028 850-tet beam of BASELINE.json configs[2] from rest under the ramped load, resident kernel (1000-step
 launches) against the CPU oracle (reference element matrices applied element by element, fem_oracle.MatrixFreeStiffness):
@@ -13,11 +13,12 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 from oracle import fem_oracle as fo  # noqa: E402
 from bench import ALPHA, build_rank_solver  # noqa: E402
-from synchronization_avoiding_algorithms_amd.mesh import structured_beam  # noqa: E402
+from synchronization_avoiding_algorithms_amd.mesh import delaunay_beam, structured_beam  # noqa: E402
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
 marks = [m for m in (100, 300, 1000, 2000, 3000, 5000, 10000) if m <= steps]
-mesh = structured_beam(19)
+# "delaunay": the same box meshed without any lattice (bench.py --mesh delaunay, the `unstructured` leg)
+mesh = delaunay_beam(19) if "delaunay" in sys.argv[2:] else structured_beam(19)
 sol, lay, _, dt = build_rank_solver(mesh, 1, 0, 0)
 from synchronization_avoiding_algorithms_amd import fem_setup as fs  # noqa: E402
 
