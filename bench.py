@@ -23,7 +23,8 @@ Extra objects on the N = 1 line:
                 `hbm_measured`) and what really bounds it (`bound`, `onchip`: VALU / LDS / barrier shares and fp64 rate
                 from the committed PMC passes of the same kernel - printed only while the plan of this run is the
                 profiled one).
-  cache_exceeding   BASELINE.json's 8.2M-tet beam on ONE GPU (exceeds the Infinity Cache; one fused launch per step).
+  cache_exceeding   BASELINE.json's 8.2M-tet beam on ONE GPU (exceeds the Infinity Cache; fused kernel, split stepping on
+                three streams, with the one-launch-per-step figure beside it).
   per_gpu_of_8      the per-GPU workload of configs[3] / configs[4]: rank 3 of the 8 x-slabs of that beam, stepped plain,
                 through the peer exchange with loop-back neighbours, through saa_step_synced with a one-rank RCCL
                 communicator (eager launches / replayed graphs) and through sync-avoiding windows (native predictor at
