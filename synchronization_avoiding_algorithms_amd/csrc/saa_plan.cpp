@@ -896,6 +896,7 @@ int32_t joint_pack_list(const uint16_t *items, int32_t n_items, JointState &js, 
   };
   int32_t done = 0, remaining = n_items;
   int32_t pad_budget = static_cast<int32_t>(pad * n_items);  // idle lanes allowed instead of clashes (reorder_for_lds: `pad`)
+  std::vector<int32_t> bucket[6];
   while (remaining > 0) {
     out.resize(8 * static_cast<size_t>(done + kHalf), 0);
     for (int32_t l = 0; l < kHalf; ++l) out[8 * static_cast<size_t>(done + l) + 5] = 2;
@@ -909,13 +910,18 @@ int32_t joint_pack_list(const uint16_t *items, int32_t n_items, JointState &js, 
     auto pick = [&](uint16_t v, int g, int a) -> int {
       const bool owned = v < n_owned;
       const int32_t *room = owned ? js.room_owned : js.room_halo;
+      // residues whose bank is free for the group's reads (both halves of the 32: c and c + 16 share a read bank) and, for
+      // an owned node, for the half's atomics
+      uint32_t ok = ~(taken_rd[g][a] | (taken_rd[g][a] << 16));
+      if (owned) ok &= ~taken_at[a];
       int best = -1, best_room = 0;
-      for (int c = 0; c < 32; ++c) {
-        if (room[c] <= best_room) continue;
-        if ((taken_rd[g][a] >> (c & 15)) & 1u) continue;
-        if (owned && ((taken_at[a] >> c) & 1u)) continue;
-        best = c;
-        best_room = room[c];
+      while (ok) {
+        const int c = __builtin_ctz(ok);
+        ok &= ok - 1;
+        if (room[c] > best_room) {
+          best = c;
+          best_room = room[c];
+        }
       }
       return best;
     };
@@ -955,14 +961,20 @@ int32_t joint_pack_list(const uint16_t *items, int32_t n_items, JointState &js, 
     };
     const int32_t lim = std::min<int32_t>(static_cast<int32_t>(pool.size()), kWindow);
     // clash-free placements: first the items whose nodes are all fixed (sweep 0), then those with one free node, two, ...
+    // (the window sorted into those classes once per half, as the numbering stands at its start)
+    for (auto &b : bucket) b.clear();
+    for (int32_t p = 0; p < lim; ++p) {
+      const uint16_t *it = items + 8 * static_cast<size_t>(pool[p]);
+      int n_free = 0;
+      for (int a = 0; a < (it[5] ? 5 : 4); ++a) n_free += js.res[it[a]] < 0;
+      bucket[n_free].push_back(p);
+    }
     for (int sweep = 0; sweep <= 5 && placed < kHalf; ++sweep)
-      for (int32_t p = 0; p < lim && placed < kHalf; ++p) {
+      for (size_t bi = 0; bi < bucket[sweep].size() && placed < kHalf; ++bi) {
+        const int32_t p = bucket[sweep][bi];
         if (pool[p] < 0) continue;
         const uint16_t *it = items + 8 * static_cast<size_t>(pool[p]);
         const int real = it[5] ? 5 : 4;
-        int n_free = 0;
-        for (int a = 0; a < real; ++a) n_free += js.res[it[a]] < 0;
-        if (n_free != sweep) continue;
         bool ok = false;
         for (int q = 0; q < n_syms(it) && !ok; ++q) {
           uint16_t v[5];
