@@ -1031,6 +1031,9 @@ def main():
                          "ncclAllReduce from C++, torch = torch.distributed.all_reduce; auto tries them in that order")
     ap.add_argument("--same-device", action="store_true",
                     help="rehearsal on a one-GPU box: every rank uses cuda:0 (needs --backend gloo)")
+    ap.add_argument("--no-split-stepping", action="store_true",
+                    help="plans of four rounds of workgroups and more: one launch of all blocks per step instead of the three "
+                         "block sets on three streams (profiling passes: one dispatch per step to count)")
     ap.add_argument("--preflight", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--force-preflight", action="store_true", help=argparse.SUPPRESS)  # tests: preflight with --same-device
     ap.add_argument("--force-rccl-leg", action="store_true", help=argparse.SUPPRESS)   # tests: the RCCL leg on gloo
@@ -1105,6 +1108,8 @@ def main():
         part = PartitionedSolver(mesh.points, mesh.tets, mesh.triangles, epart, rank, world, E=E, nu=NU, rho=RHO,
                                  fz=FZ, alpha=ALPHA, gamma=GAMMA, device=local_rank, block_nodes=args.block_nodes,
                                  threads=args.threads, exchange=how)
+        if args.no_split_stepping and hasattr(part.solver, "set_option"):
+            part.solver.set_option("split_stepping", 0)
         if synced_graph is not None and hasattr(part.solver, "set_option"):
             part.solver.set_option("synced_graph", synced_graph)  # saa_step_synced: replayed graphs / eager launches
         part.step_synced(args.warmup)  # world == 1: plain steps; else one exchange of shared-node forces per step

@@ -22,7 +22,7 @@ stats)
   (cd /tmp && export TMPDIR=/tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $out/stats -o run --output-format csv -- python3 $root/bench.py --gpus 1 --steps 20 --warmup 5 --legs roofline > $out/stats.log 2>&1; echo "rocprofv3 exit status $?" >> $out/stats.log)
   ;;
 pmc19) tools/pmc_collect.sh r04_resident19 19 --warmup 1000 ;;
-pmc38) tools/pmc_collect.sh r04_fused38 38 --steps 200 --warmup 50 ;;
+pmc38) tools/pmc_collect.sh r04_fused38 38 --steps 200 --warmup 50 --no-split-stepping ;;
 pmcdel) tools/pmc_collect.sh r04_resident19_delaunay 19 --warmup 1000 --mesh delaunay ;;
 stamps)
   python tools/persist_stamps.py 19 --json=$out/resident_stamps.json > $out/resident_stamps.txt 2>&1
