@@ -67,11 +67,10 @@ PLAN_IDENTITY = ("n_blocks", "max_owned", "max_local", "n_elem_copies", "n_halo_
 def test_hook(point):
     """Tests only: ``SAA_BENCH_HOOKS=<module>`` (tests/bench_hooks.py) lets a test misbehave at a named point of the run
     (a preflight child that hangs, a collective that never returns); nothing of that lives in this file."""
-    name = os.environ.get("SAA_BENCH_HOOKS")
-    if name:
-        import importlib
+    if os.environ.get("SAA_BENCH_HOOKS") == "tests.bench_hooks":  # (that one module, nothing else)
+        from tests import bench_hooks
 
-        importlib.import_module(name).hook(point)
+        bench_hooks.hook(point)
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -677,26 +677,34 @@ int split_steps(saa_solver *s, int32_t nsteps) {
   }
   hipStream_t sl = s->split_stream[0], sm = s->split_stream[1], sr = s->split_stream[2];
   hipEvent_t el = s->split_ev[0], em = s->split_ev[1], er = s->split_ev[2];
-  for (int32_t k = 0; k < nsteps; ++k) {
+  hipError_t err = hipSuccess;
+  auto ok = [&](hipError_t e) {
+    if (e != hipSuccess && err == hipSuccess) err = e;
+    return err == hipSuccess;
+  };
+  for (int32_t k = 0; k < nsteps && err == hipSuccess; ++k) {
     s->set_ramp();
     const double *d0 = s->dbuf[s->i0].p, *dn = s->dbuf[s->in_].p;
     double *d1 = s->dbuf[s->i1].p;
     if (k > 0) {  // (the events still hold the records of step k - 1)
-      HIP_TRY(hipStreamWaitEvent(sm, el, 0));
-      HIP_TRY(hipStreamWaitEvent(sm, er, 0));
-      HIP_TRY(hipStreamWaitEvent(sl, em, 0));
-      HIP_TRY(hipStreamWaitEvent(sr, em, 0));
+      if (!ok(hipStreamWaitEvent(sm, el, 0)) || !ok(hipStreamWaitEvent(sm, er, 0)) || !ok(hipStreamWaitEvent(sl, em, 0)) ||
+          !ok(hipStreamWaitEvent(sr, em, 0)))
+        break;
     }
     saa::launch_fused_step(m[1], s->threads, s->lds_bytes, sm, d0, dn, d1, nullptr, nullptr, nullptr, s->consts);
     saa::launch_fused_step(m[0], s->threads, s->lds_bytes, sl, d0, dn, d1, nullptr, nullptr, nullptr, s->consts);
     saa::launch_fused_step(m[2], s->threads, s->lds_bytes, sr, d0, dn, d1, nullptr, nullptr, nullptr, s->consts);
-    HIP_TRY(hipEventRecord(em, sm));
-    HIP_TRY(hipEventRecord(el, sl));
-    HIP_TRY(hipEventRecord(er, sr));
+    if (!ok(hipEventRecord(em, sm)) || !ok(hipEventRecord(el, sl)) || !ok(hipEventRecord(er, sr))) break;
     s->rotate();
     s->tn = s->tn + s->consts.dt;  // Data_prepare.py:235
   }
-  for (int j = 0; j < 3; ++j) HIP_TRY(hipStreamWaitEvent(s->stream, s->split_ev[j], 0));
+  // the caller's stream continues behind all three sets - also when something failed on the way: nothing enqueued later
+  // may overtake what is in flight
+  for (int j = 0; j < 3; ++j) {
+    (void)hipEventRecord(s->split_ev[j], s->split_stream[j]);
+    (void)hipStreamWaitEvent(s->stream, s->split_ev[j], 0);
+  }
+  if (err != hipSuccess) return fail(SAA_E_HIP, std::string("split stepping: ") + hipGetErrorString(err));
   return check_launch();
 }
 
