@@ -16,8 +16,8 @@ translation and infinitesimal rotation produce no force).
 
 Tolerances (fp64): K.d rel-L2 < 1e-13; 200 steps (100 on the N = 2 / N = 4 slabs) from a rough state rel-L2 < 1e-11 (both
 kernels, against the oracle and against each other); rigid modes: max|f| < 1e-12 x max|K.d_rand| for displacements of the
-same size.  Every stepping test of this file compares with the oracle; only the 8.2M-tet beam on one GPU, which no oracle
-run reaches in test time, stands on size-independent properties alone.
+same size.  Every stepping test of this file compares with the oracle - since round 4 also the 8.2M-tet beam on one GPU (30 steps
+in the suite, 100 outside it), next to its size-independent properties.
 """
 import numpy as np
 import pytest
@@ -350,6 +350,35 @@ def test_eight_million_tets_on_one_gpu_properties_of_the_fused_plan(beam38):
             want = min(tn, 1.0) * f[comp::3].sum()
             assert abs(lhs[comp::3].sum() - want) < 1e-9 * np.abs(m[comp::3] * (r - 2 * q + p)[comp::3] / dt ** 2).sum(), (j, comp)
         tn = tn + dt
+    sol.close()
+
+
+def test_eight_million_tets_on_one_gpu_against_the_oracle(beam38):
+    """The cache-exceeding point of the bench once more, now WITH the oracle (round 4: an oracle step of 8.2M tets takes
+    0.3 s on the GPU box's host with 16 threads, the operator 9.5 GB): K.d and 30 steps from a rough state, stepped as
+    three block sets on three streams (split stepping, the default at this size) and with one launch of all blocks per
+    step; 100 steps outside the suite: profiles/r04_long_parity_8M_tets.txt."""
+    from oracle import fem_oracle as fo
+
+    sol, lay, dt, l_M, F, (lmd, mu) = _build(beam38, 1, 0)
+    st = sol.plan_stats()
+    assert st["n_blocks"] == 2048 and st["threads"] == 512 and not sol.resident_kernel_info()["capable"]
+    K = fo.MatrixFreeStiffness(lay.cells_local, beam38.points[lay.nodes], lmd, mu, threads=16)
+    rng = np.random.default_rng(38)
+    d = rng.uniform(-1e-2, 1e-2, size=(sol.n_dof, 1))
+    assert rel_l2(sol.internal_force(d), K.dot(d)) < 1e-13
+    d0, dn = _rough_state(sol.n_dof, lay.dirichlet_dofs, rng)
+    steps = 30
+    tn, o0, on = 0.25, d0, dn
+    for _ in range(steps):
+        o1 = fo.explicit_step(K, F, lay.dirichlet_dofs, tn, dt, o0, on, l_M, ALPHA)
+        on, o0, tn = o0, o1, tn + dt
+    for split in (1, 0):
+        sol.set_option("split_stepping", split)
+        sol.set_state(d0, dn, 0.25)
+        sol.step(steps)
+        g0, gn, gt = sol.get_state()
+        assert gt == tn and rel_l2(g0, o0) < 1e-11 and rel_l2(gn, on) < 1e-11, split
     sol.close()
 
 
