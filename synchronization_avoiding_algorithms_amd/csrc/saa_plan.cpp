@@ -344,10 +344,10 @@ int32_t build_items(const std::vector<uint16_t> &loc, int32_t n_elem, int32_t n_
     }
   }
   // Unstructured meshes: the greedy pass leaves 5-10 % of the elements single (a Delaunay mesh of random points: 10 %),
-  // and a single costs a lane as much as a pair.  Augmenting paths of length three - single s, its neighbour f matched
-  // with g, g's other neighbour t single: (s,f) (g,t) instead of (f,g) - and, in a second sweep, of length five pick most
-  // of them up; here an all-owned element may also pair with one that has halo nodes (the item then waits for the halo
-  // records like its second element would have).  Only on request (`augment`: the caller asks when more than 1.5 % of a
+  // and a single costs a lane as much as a pair.  Augmenting paths - single s, its neighbour f matched with g, g's other
+  // neighbour t single: (s,f) (g,t) instead of (f,g), and longer chains of such exchanges - pick nearly all of them up
+  // (99.6 % of the element copies paired); here an all-owned element may also pair with one that has halo nodes (the item
+  // then waits for the halo records like its second element would have).  Only on request (`augment`: the caller asks when more than 1.5 % of a
   // block's elements stayed single): on lattices (99.8 % paired) the pairing stays exactly what the pattern classes of
   // the LDS packing were tuned on.
   if (augment && n_single > 0) {
