@@ -104,15 +104,17 @@ int32_t choose_block_count(int32_t n_nodes, int32_t block_nodes) {
 
 // Automatic block size (measured on MI355X, pair kernel).  Larger blocks duplicate fewer border elements and
 // stage fewer halo records per owned node (element copies 1.25x at ~740 owned nodes against 1.41x at ~380).
-//   * up to ~215k nodes (one MI355X-sized partition of ~1M tets) every CU gets exactly ONE block and all 256
-//     run as a single wave of 1024-thread workgroups (1M tets: 13.0 us/step; 512 blocks of 372: 16.3).  840 nodes per
-//     block on average is what the resident kernel's LDS image still holds with the usual +14 % of the fullest block
-//     (~168 B per owned node on a Delaunay mesh, ~160 on a lattice: 160 KB / 168 B = 975 nodes); round 4 raised it from
-//     760, where a 209k-node Delaunay mesh fell to 512 blocks of 512 threads outside the resident kernel (15.5 us/step);
+//   * up to ~360k nodes every CU gets exactly ONE block and all 256 run as a single wave of 1024-thread workgroups (1M
+//     tets: 13.0 us/step; 512 blocks of 372: 16.3).  Up to ~215k nodes (840 per block on average, +14 % in the fullest)
+//     the resident kernel's LDS image holds the block (~165 B per owned node of 160 KB): a 209k-node Delaunay mesh
+//     runs resident at 9.0 us/step, a 215k-node one at 9.8 - round 3 stopped at 760 per block and sent them to 512 blocks
+//     of 512 threads outside the resident kernel (15.5 / 15.7).  Beyond that the one-launch-per-step kernel takes the same
+//     256 blocks (its image is 48 B per local + 24 B per owned node) and still beats the smaller blocks by 12 % (243k
+//     nodes: 15.5 against 17.8 us, 255k: 16.6 against 18.7; tools/capacity_point.py);
 //   * larger partitions take ~720-node blocks in several rounds of 512-thread workgroups, which overlap each
 //     other's memory and LDS phases (8.2M tets: 84.6 us/step; 377-node blocks 91.5; 942-node blocks 118).
 int32_t auto_block_nodes(int32_t n_nodes) {
-  constexpr int32_t kCUs = 256, kBig = 840;
+  constexpr int32_t kCUs = 256, kBig = 1400;
   if (n_nodes <= kDefaultBlockNodes) return n_nodes;  // tiny mesh: one block
   if (n_nodes <= kCUs * kBig) return std::max<int32_t>(96, (n_nodes + kCUs - 1) / kCUs);
   return kLargeMeshBlockNodes;
