@@ -403,3 +403,62 @@ def test_eight_ranks_on_the_eight_slab_partition_match_the_oracle(tmp_path):
         loc = fo.node_to_dof(fo.local_index(shared[r], ranks[r].nodes))
         assert np.array_equal(got["hist_last"], got["d"][loc])            # history row = the shared dofs after the step
     assert max(np.abs(d[:, 0]).max() for d in d0s) > 0
+
+
+_H8 = dict(steps=70, n_p=2, n_f=2, n_s=5, hid=8, smax=2e-9, smin=-2e-9)  # warm-up 10 steps, windows of 10 steps
+
+
+def _eight_rank_hybrid_worker(rank, world, port, out_dir):
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from cpu_double import CpuSolverDouble, host_setup_fields
+    from synchronization_avoiding_algorithms_amd import predictor as pr
+    from synchronization_avoiding_algorithms_amd.distributed import PartitionedSolver, run_hybrid
+    from synchronization_avoiding_algorithms_amd.mesh import slab_partition, structured_beam
+
+    mesh = structured_beam(2)
+    part = PartitionedSolver(mesh.points, mesh.tets, mesh.triangles, slab_partition(mesh, world), rank, world,
+                             tensor_device=torch.device("cpu"), solver_factory=lambda **kw: CpuSolverDouble(**kw),
+                             setup_fields=host_setup_fields)
+    torch.manual_seed(100 + rank)  # every rank its own model (Online_predictor.py:139-141), reproducible in the checker
+    model = pr.LSTM_encoder_decoder(part.input_size, _H8["hid"])
+    predictor = pr.DevicePredictor(model, _H8["n_p"], _H8["n_f"], _H8["n_s"], _H8["smax"], _H8["smin"])
+    hist = run_hybrid(part, _H8["steps"], predictor, _H8["n_p"], _H8["n_f"], _H8["n_s"])
+    np.savez(os.path.join(out_dir, f"h{rank}.npz"), d=part.get_state()[0][:, 0], hist=hist.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_eight_ranks_sync_avoiding_loop_matches_the_oracle(tmp_path):
+    """BASELINE.json's configs[4] in shape - 8 ranks, each with its own LSTM, 10 synchronised steps and then windows of 10
+    steps without any exchange (Online_predictor.py:251-318) - on the CPU with gloo, against the oracle's loop with the same
+    eight seeded models evaluated batch-1 like the reference does (fp32 LSTM, batched vs batch-1: 1e-5)."""
+    from oracle import fem_oracle as fo
+    from oracle import lstm_oracle as lo
+    from synchronization_avoiding_algorithms_amd import predictor as pr
+    from synchronization_avoiding_algorithms_amd.mesh import slab_partition, structured_beam
+
+    world = 8
+    port = free_port()
+    mp.spawn(_eight_rank_hybrid_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    mesh = structured_beam(2)
+    ranks, dt, shared, _ = fo.setup_problem(mesh.points, mesh.tets, mesh.triangles, world, slab_partition(mesh, world))
+    loc = [fo.node_to_dof(fo.local_index(shared[r], ranks[r].nodes)) for r in range(world)]
+    models = []
+    for r in range(world):
+        torch.manual_seed(100 + r)
+        sd = pr.LSTM_encoder_decoder(len(loc[r]), _H8["hid"]).state_dict()
+        models.append(lo.load_model(len(loc[r]), _H8["hid"], sd))
+
+    def predictor(r, n, hist):
+        return lo.predictor_table(n, models[r], _H8["n_p"], _H8["n_f"], _H8["n_s"], len(loc[r]), hist, _H8["smax"], _H8["smin"])
+
+    save, hist = fo.run_hybrid(ranks, dt, _H8["steps"], loc, predictor, _H8["n_p"], _H8["n_f"], _H8["n_s"])
+    for r in range(world):
+        got = np.load(tmp_path / f"h{r}.npz")
+        assert rel_l2(got["hist"][:10], hist[r][:10]) < 1e-13            # the synchronised warm-up
+        assert rel_l2(got["hist"], hist[r]) < 1e-5 and rel_l2(got["d"], save[r][:, -1]) < 1e-5, r
+        assert np.abs(got["hist"][10:]).max() > 0                        # the windows did overwrite the shared dofs
