@@ -1178,8 +1178,10 @@ def main():
         "ms_per_step": 1e3 * elapsed / args.steps, "steps_per_s": args.steps / elapsed,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
         "data": "synthetic",
-        "config": {"workload": f"synthetic 25n x n x n Kuhn-tet cantilever n={n}"
-                               f"{' (nodes jittered, numbering shuffled)' if args.mesh == 'jittered' else ''}: "
+        "config": {"workload": ("synthetic cantilever, Delaunay tetrahedra of random points in the 25 x 1 x 1 box at the "
+                                f"node count of n={n}" if args.mesh == "delaunay" else
+                                f"synthetic 25n x n x n Kuhn-tet cantilever n={n}"
+                                f"{' (nodes jittered, numbering shuffled)' if args.mesh == 'jittered' else ''}") + ": "
                                f"{ne_total} tets, {nn_total} nodes, {world} x-slab partition(s), fp64, E=1e6 nu=0.3 "
                                f"alpha=0.5 ramped body force, dt={dt:.6e}",
                    "exchange": "none (1 partition)" if world == 1 else
