@@ -78,3 +78,13 @@ def test_files_equal_the_ones_h5py_wrote(tmp_path):
         x, y = open(gold, "rb").read(), open(mine, "rb").read()
         if hdf5_c.library_version()[:2] == (1, 10):  # (another library version lays the file out differently)
             assert len(x) == len(y) and _mask_mtime(x) == _mask_mtime(y), name
+
+
+def test_without_any_hdf5_library_the_npz_stand_in_is_written(tmp_path, monkeypatch):
+    """No h5py and no libhdf5 (another host): the same array under the same key in `<name>.npz`, and the path says so."""
+    monkeypatch.setattr(hdf5_c, "available", lambda: False)
+    monkeypatch.setattr(rio, "_h5py", lambda: None)
+    a = np.arange(24.0).reshape(6, 4)
+    path = rio.save_displacement(str(tmp_path / "Modeled_Local-rank-0.hdf5"), a)
+    assert path.endswith(".npz") and not os.path.exists(tmp_path / "Modeled_Local-rank-0.hdf5")
+    assert np.array_equal(rio.load_displacement(str(tmp_path / "Modeled_Local-rank-0.hdf5")), a)
