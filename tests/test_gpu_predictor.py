@@ -150,3 +150,34 @@ def test_arguments_are_checked():
     # n_s = 1 (the reference's windows then hold n_p - 1 rows): DevicePredictor keeps the PyTorch path
     assert pr.DevicePredictor(model, 4, 3, 1, 1.0, -1.0).backend != "native HIP"
     nat.close()
+
+
+def test_widths_beyond_round_3s_limit_and_the_fall_back():
+    """Round 3 refused input sizes above 23 170 (a size check far stricter than what the kernels index with 32 bits): a
+    large k-way partition's width, 30 000 inputs = 10 000 shared nodes, now runs on the library's kernels and agrees with the
+    PyTorch-ROCm route; a model the kernels do not take (hidden size above 128) makes DevicePredictor say so once and use
+    the PyTorch route."""
+    import warnings
+
+    I, H, n_p, n_f, n_s = 30000, 16, 3, 3, 6
+    torch.manual_seed(5)
+    model = pr.LSTM_encoder_decoder(I, H).cuda().eval()
+    gen = torch.Generator(device="cuda").manual_seed(6)
+    hist = torch.cumsum(torch.randn(n_p * n_s + 9, I, generator=gen, device="cuda", dtype=torch.float64) * 1e-4, 0)
+    smax, smin = float(hist.max()) * 1.1, float(hist.min()) * 1.1
+    n = n_p * n_s + 4
+    nat = pr.NativePredictor(model, n_p, n_f, n_s)
+    got = nat.predict(n, hist, smax, smin)
+    with torch.no_grad():
+        want = pr.predict_table(model, n, n_p, n_f, n_s, hist, smax, smin)
+    assert float((got - want).abs().max()) <= 1e-4 * float(want.abs().max())
+    nat.close()
+    wide = pr.LSTM_encoder_decoder(12, 200).cuda().eval()  # 1600 gate rows: more than one thread per row allows
+    h2 = torch.cumsum(torch.randn(40, 12, device="cuda", dtype=torch.float64) * 1e-4, 0)
+    dev = pr.DevicePredictor(wide, 3, 3, 6, 1e-3, -1e-3)
+    with warnings.catch_warnings(record=True) as caught, torch.no_grad():
+        warnings.simplefilter("always")
+        table = dev(30, h2)
+        want = pr.predict_table(wide, 30, 3, 3, 6, h2, 1e-3, -1e-3)
+    assert any("native predictor refused" in str(w.message) for w in caught) and dev.backend.startswith("PyTorch-ROCm")
+    assert torch.allclose(table, want, rtol=1e-6, atol=1e-12)
