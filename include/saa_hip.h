@@ -86,7 +86,7 @@ typedef struct saa_plan_stats {
 } saa_plan_stats;
 
 const char *saa_last_error(void);
-/* Library / ABI version; bumps when this header changes (2: peer exchange and resident-kernel entry points; 3: loop-back attach; 4: partitioner and set-up kernels; 5: deterministic mode; 6: copy-bandwidth aid; 7: saa_plan_stats grew; 8: saa_predictor_*, saa_topology_*; 9: saa_set_option, saa_plan_stats.n_renumbered). */
+/* Library / ABI version; bumps when this header changes (2: peer exchange and resident-kernel entry points; 3: loop-back attach; 4: partitioner and set-up kernels; 5: deterministic mode; 6: copy-bandwidth aid; 7: saa_plan_stats grew; 8: saa_predictor_*, saa_topology_*; 9: saa_set_option, saa_plan_stats.n_renumbered; 10: saa_plan_host_check). */
 int32_t saa_abi_version(void);
 
 /* Element partition, one part per rank / GPU: the role of `_, epart = part_mesh_kway(size, eptr, eind)` (mgmetis /
@@ -126,6 +126,13 @@ int saa_plan_stats_get(const saa_solver *s, saa_plan_stats *out);
 /* Host-only plan builder (no HIP call): same decomposition saa_create uses, for CPU tests. */
 int saa_plan_host_stats(int32_t n_nodes, int32_t n_elems, const double *xyz, const int32_t *tets,
                         int32_t block_nodes, saa_plan_stats *out);
+/* Self-check of the block plan the library would build for this partition (host only, no GPU): the internal numbering is a
+ * permutation; every work item names valid nodes, its tets are elements of the mesh in the mesh's orientation (the signed
+ * detJ of Mat_construction.py:93), first-round items name owned nodes only; every element appears exactly once in every
+ * block owning one of its nodes and nowhere else.  *violations_out = number of failed checks (0: the plan is what the step
+ * kernels assume).  No reference counterpart (its LocalK is an assembled matrix); used by the CPU tests. */
+int saa_plan_host_check(int32_t n_nodes, int32_t n_elems, const double *xyz, const int32_t *tets, int32_t block_nodes,
+                        int64_t *violations_out);
 
 /* All later work of this handle goes to `hip_stream` (a hipStream_t; NULL = null stream). */
 int saa_set_stream(saa_solver *s, void *hip_stream);

@@ -20,7 +20,7 @@ HEADER = os.path.join(os.path.dirname(_HERE), "include", "saa_hip.h")
 SOURCES = ["saa_plan.cpp", "saa_partition.cpp", "saa_kernels.hip", "saa_setup.hip", "saa_predictor.hip", "saa_topology.hip", "saa_api.cpp"]
 HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics", "-ldl"]
 
-ABI_VERSION = 9  # what saa_abi_version() of a matching library returns (include/saa_hip.h)
+ABI_VERSION = 10  # what saa_abi_version() of a matching library returns (include/saa_hip.h)
 SAA_OK, SAA_E_ARG, SAA_E_HIP, SAA_E_STATE, SAA_E_CAPACITY = 0, -1, -2, -3, -4
 
 
@@ -78,6 +78,7 @@ SIGNATURES = {
     "saa_destroy": (C.c_int, [_H]),
     "saa_plan_stats_get": (C.c_int, [_H, C.POINTER(PlanStats)]),
     "saa_plan_host_stats": (C.c_int, [C.c_int32, C.c_int32, _dp, _ip, C.c_int32, C.POINTER(PlanStats)]),
+    "saa_plan_host_check": (C.c_int, [C.c_int32, C.c_int32, _dp, _ip, C.c_int32, C.POINTER(C.c_int64)]),
     "saa_set_stream": (C.c_int, [_H, C.c_void_p]),
     "saa_set_state": (C.c_int, [_H, _dp, _dp, C.c_double]),
     "saa_get_state": (C.c_int, [_H, _dp, _dp, _dp]),

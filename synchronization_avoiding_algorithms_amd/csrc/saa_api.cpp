@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <iterator>
 #include <mutex>
 #include <new>
 #include <numeric>
@@ -793,7 +794,7 @@ extern "C" {
 
 const char *saa_last_error(void) { return g_last_error.c_str(); }
 
-int32_t saa_abi_version(void) { return 9; }  // 4: saa_part_mesh_kway, saa_setup_fields; 5: saa_set_deterministic; 6: saa_device_copy_bandwidth; 7: saa_plan_stats grew; 8: saa_predictor_*, saa_topology_*; 9: saa_set_option, saa_plan_stats.n_renumbered
+int32_t saa_abi_version(void) { return 10; }  // 4: saa_part_mesh_kway, saa_setup_fields; 5: saa_set_deterministic; 6: saa_device_copy_bandwidth; 7: saa_plan_stats grew; 8: saa_predictor_*, saa_topology_*; 9: saa_set_option, saa_plan_stats.n_renumbered; 10: saa_plan_host_check
 
 int saa_device_copy_bandwidth(int32_t device, int64_t n_bytes, int32_t reps, double *bytes_per_s) {
   if (!bytes_per_s || n_bytes < 16 || reps < 1) return fail(SAA_E_ARG, "saa_device_copy_bandwidth: bad argument");
@@ -813,6 +814,115 @@ int saa_plan_host_stats(int32_t n_nodes, int32_t n_elems, const double *xyz, con
   std::string err;
   if (!build_fitting_plan(n_nodes, n_elems, xyz, tets, block_nodes, plan, err)) return fail(SAA_E_ARG, err);
   fill_stats(plan, lds_bytes_of(plan), pick_threads(plan, 0), out);
+  return SAA_OK;
+}
+
+// Self-check of a block plan against the mesh it was built from (host only): what the step kernels rely on.
+//   1. the internal numbering is a permutation of the caller's;
+//   2. every work item names valid block-local nodes, its one or two tets are elements of the mesh (same four nodes) with the
+//      orientation the mesh gives them (the sign of detJ is kept, Mat_construction.py:93), first-round items name owned nodes only;
+//   3. every element appears exactly once in every block that owns one of its nodes, and nowhere else (owner computes: a node's
+//      force is complete inside its block, nothing is summed across workgroups).
+// *violations_out: how many of these checks failed (0 = the plan is what the kernels assume).
+int saa_plan_host_check(int32_t n_nodes, int32_t n_elems, const double *xyz, const int32_t *tets, int32_t block_nodes,
+                        int64_t *violations_out) {
+  if (!violations_out) return fail(SAA_E_ARG, "saa_plan_host_check: null out");
+  saa::Plan plan;
+  std::string err;
+  if (!build_fitting_plan(n_nodes, n_elems, xyz, tets, block_nodes, plan, err)) return fail(SAA_E_ARG, err);
+  int64_t bad = 0;
+  {  // 1
+    std::vector<char> seen(n_nodes, 0);
+    for (int32_t i = 0; i < n_nodes; ++i) {
+      const int32_t o = plan.new_to_old[i];
+      if (o < 0 || o >= n_nodes || seen[o] || plan.old_to_new[o] != i) ++bad;
+      else seen[o] = 1;
+    }
+  }
+  const int32_t nb = static_cast<int32_t>(plan.blocks.size());
+  std::vector<int32_t> start(nb);
+  for (int32_t b = 0; b < nb; ++b) start[b] = plan.blocks[b].node_start;
+  auto owner = [&](int32_t g) { return static_cast<int32_t>(std::upper_bound(start.begin(), start.end(), g) - start.begin()) - 1; };
+  // elements by their sorted (caller-numbered) nodes
+  struct Key {
+    int32_t v[4];
+    bool operator<(const Key &o) const { return std::lexicographical_compare(v, v + 4, o.v, o.v + 4); }
+    bool operator==(const Key &o) const { return std::equal(v, v + 4, o.v); }
+  };
+  std::vector<std::pair<Key, int32_t>> elems(n_elems);
+  for (int32_t e = 0; e < n_elems; ++e) {
+    Key k;
+    for (int a = 0; a < 4; ++a) k.v[a] = tets[4 * static_cast<size_t>(e) + a];
+    std::sort(k.v, k.v + 4);
+    elems[e] = {k, e};
+  }
+  std::sort(elems.begin(), elems.end());
+  auto det = [&](const int32_t n[4]) {  // 6 x signed volume in the caller's numbering
+    const double *p0 = xyz + 3 * static_cast<size_t>(n[0]), *p1 = xyz + 3 * static_cast<size_t>(n[1]),
+                 *p2 = xyz + 3 * static_cast<size_t>(n[2]), *p3 = xyz + 3 * static_cast<size_t>(n[3]);
+    const double a[3] = {p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2]}, b[3] = {p2[0] - p0[0], p2[1] - p0[1], p2[2] - p0[2]},
+                 c[3] = {p3[0] - p0[0], p3[1] - p0[1], p3[2] - p0[2]};
+    return a[0] * (b[1] * c[2] - b[2] * c[1]) - a[1] * (b[0] * c[2] - b[2] * c[0]) + a[2] * (b[0] * c[1] - b[1] * c[0]);
+  };
+  std::vector<std::pair<int32_t, int32_t>> copies;  // (element, block) of every tet found in the item lists
+  for (int32_t b = 0; b < nb; ++b) {
+    const saa::BlockDesc &d = plan.blocks[b];
+    auto global = [&](uint16_t l) -> int32_t {  // caller's id of block-local node l, -1 if l is out of range
+      if (l < d.n_owned) return plan.new_to_old[d.node_start + l];
+      if (l < d.n_owned + d.n_halo) return plan.new_to_old[plan.halo_ids[d.halo_off + (l - d.n_owned)]];
+      return -1;
+    };
+    for (int32_t i = 0; i < d.n_elem; ++i) {
+      const uint16_t *it = &plan.conn[8 * static_cast<size_t>(d.elem_off + i)];
+      if (it[5] == 2) continue;  // idle lane
+      const int n_tets = it[5] == 1 ? 2 : 1;
+      // A = (a; p, q, r), B = (b; p, r, q)
+      const uint16_t loc[2][4] = {{it[0], it[1], it[2], it[3]}, {it[4], it[1], it[3], it[2]}};
+      for (int t = 0; t < n_tets; ++t) {
+        int32_t n[4];
+        bool ok = true, any_owned = false, all_owned = true;
+        for (int a = 0; a < 4; ++a) {
+          n[a] = global(loc[t][a]);
+          ok = ok && n[a] >= 0;
+          any_owned = any_owned || loc[t][a] < d.n_owned;
+          all_owned = all_owned && loc[t][a] < d.n_owned;
+        }
+        if (!ok || !any_owned || (i < d.n_interior && !all_owned)) {
+          ++bad;
+          continue;
+        }
+        Key k;
+        std::copy(n, n + 4, k.v);
+        std::sort(k.v, k.v + 4);
+        auto hit = std::lower_bound(elems.begin(), elems.end(), std::make_pair(k, INT32_MIN));
+        if (hit == elems.end() || !(hit->first == k)) {
+          ++bad;  // not an element of the mesh
+          continue;
+        }
+        const int32_t e = hit->second;
+        int32_t orig[4];
+        for (int a = 0; a < 4; ++a) orig[a] = tets[4 * static_cast<size_t>(e) + a];
+        if ((det(n) > 0) != (det(orig) > 0)) ++bad;  // orientation changed
+        copies.emplace_back(e, b);
+      }
+    }
+  }
+  std::sort(copies.begin(), copies.end());
+  for (size_t i = 1; i < copies.size(); ++i) bad += copies[i] == copies[i - 1];  // an element twice in one block
+  copies.erase(std::unique(copies.begin(), copies.end()), copies.end());
+  std::vector<std::pair<int32_t, int32_t>> want;
+  for (int32_t e = 0; e < n_elems; ++e) {
+    int32_t bl[4];
+    for (int a = 0; a < 4; ++a) bl[a] = owner(plan.old_to_new[tets[4 * static_cast<size_t>(e) + a]]);
+    std::sort(bl, bl + 4);
+    for (int a = 0; a < 4; ++a)
+      if (a == 0 || bl[a] != bl[a - 1]) want.emplace_back(e, bl[a]);
+  }
+  std::vector<std::pair<int32_t, int32_t>> diff;
+  std::set_symmetric_difference(copies.begin(), copies.end(), want.begin(), want.end(), std::back_inserter(diff));
+  bad += static_cast<int64_t>(diff.size());
+  if (static_cast<int64_t>(want.size()) != plan.n_elem_copies) ++bad;
+  *violations_out = bad;
   return SAA_OK;
 }
 

@@ -290,3 +290,14 @@ def plan_host_stats(points, cells, block_nodes=0) -> dict:
     _lib.check(lib.saa_plan_host_stats(pts.size // 3, tets.size // 4, _dptr(pts), _iptr(tets),
                                        int(block_nodes), C.byref(st)))
     return st.as_dict()
+
+
+def plan_host_check(points, cells, block_nodes=0) -> int:
+    """Number of violated invariants of the block plan the library builds for this partition (``saa_plan_host_check``: the
+    numbering is a permutation, every item's tets are mesh elements in the mesh's orientation, every element exactly once in
+    every block owning one of its nodes); 0 = sound.  No GPU needed."""
+    lib = _lib.load()
+    pts, tets = _f64(points), _i32(cells)
+    bad = C.c_int64()
+    _lib.check(lib.saa_plan_host_check(pts.size // 3, tets.size // 4, _dptr(pts), _iptr(tets), int(block_nodes), C.byref(bad)))
+    return int(bad.value)
